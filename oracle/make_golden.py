@@ -1,0 +1,152 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/avse_*.npz.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the
+reference's own `AV_Fusion_Model_Frames` (avse_model_final.py:14) through a
+harness shim -- `torchsummary` (a print-only utility, avse_model_final.py:8)
+stubbed, and the hard-coded device string "cuda" (avse_model_final.py:59,66,...)
+mapped to "cpu" -- loads the seeded weight recipe of oracle/avse_ref_cpu.py into
+it, runs forward / loss / backward / one Adam step on seeded synthetic inputs and
+stores the results as small fixtures.  It also asserts that the oracle twin
+(AVFusionFramesRef) reproduces the reference on the same inputs, which is what
+pins the oracle.  Nothing of the reference (source or bytecode) is written out:
+only numbers.
+
+    python oracle/make_golden.py            # writes tests/golden/avse_{P,S,L}.npz
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import avse_ref_cpu as orc  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+# name -> (batch, T frames, W, fft_len, hops_per_frame)
+CONFIGS = {
+    "P": (2, 8, 256, 512, 8),      # parity config
+    "S": (2, 8, 128, 256, 8),      # small: S=4, 3-layer STFT encoder
+    "L": (2, 16, 256, 512, 8),     # BASELINE config-2 clip shape (T=16) at the parity frame size
+}
+SEED = 7
+LR = 1e-3
+LOSS_COEFF = 0.001   # run_config.py:8
+
+
+@contextlib.contextmanager
+def reference_on_cpu():
+    """Make the reference importable/constructible without a GPU."""
+    stub = types.ModuleType("torchsummary")
+    stub.summary = lambda *a, **k: None
+    sys.modules["torchsummary"] = stub
+    sys.path.insert(0, REFERENCE)
+    t_to, m_to = torch.Tensor.to, torch.nn.Module.to
+
+    def fix(args):
+        return tuple("cpu" if (isinstance(a, str) and a == "cuda") else a for a in args)
+
+    torch.Tensor.to = lambda self, *a, **k: t_to(self, *fix(a), **k)
+    torch.nn.Module.to = lambda self, *a, **k: m_to(self, *fix(a), **k)
+    try:
+        yield
+    finally:
+        torch.Tensor.to, torch.nn.Module.to = t_to, m_to
+        sys.path.remove(REFERENCE)
+
+
+def run(model, x_a, x_v, y_a, y_v):
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    opt.zero_grad()
+    loss, a_loss, v_loss, (a, v, fused) = orc.loss_ref(model, x_a, x_v, y_a, y_v, LOSS_COEFF, 1)
+    loss.backward()
+    out = {
+        "x_a_out": a.detach().numpy(), "x_av_fused": fused.detach().numpy(),
+        "x_v_out_sample": v.detach().flatten()[::997].numpy(),
+        "x_v_out_sum": np.float64(v.detach().double().sum().item()),
+        "loss": np.float64(loss.item()), "a_loss": np.float64(a_loss.item()), "v_loss": np.float64(v_loss.item()),
+    }
+    names, gnorm, gsample = [], [], []
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder."):
+            continue
+        names.append(k)
+        if p.grad is None:
+            gnorm.append(-1.0)
+            gsample.append(np.zeros(8, np.float32))
+        else:
+            g = p.grad.detach().flatten()
+            gnorm.append(g.double().norm().item())
+            idx = (torch.arange(8, dtype=torch.long) * (g.numel() - 1)) // 7
+            gsample.append(g[idx].numpy())
+    out["param_names"] = np.array(names)
+    out["grad_norm"] = np.array(gnorm)
+    out["grad_sample"] = np.stack(gsample)
+    opt.step()
+    wsum, wabs = [], []
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder."):
+            continue
+        wsum.append(p.detach().double().sum().item())
+        wabs.append(p.detach().double().abs().sum().item())
+    out["adam_wsum"] = np.array(wsum)
+    out["adam_wabs"] = np.array(wabs)
+    bn_names, bn_mean, bn_var = [], [], []
+    for k, b in model.named_buffers():
+        if k.startswith("stft_autoencoder.") or k.startswith("stft_decoder."):
+            continue
+        if k.endswith("running_mean"):
+            bn_names.append(k[:-len(".running_mean")])
+            bn_mean.append(b.double().sum().item())
+        if k.endswith("running_var"):
+            bn_var.append(b.double().sum().item())
+    out["bn_names"] = np.array(bn_names)
+    out["bn_running_mean_sum"] = np.array(bn_mean)
+    out["bn_running_var_sum"] = np.array(bn_var)
+    return out
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    torch.set_num_threads(8)
+    with reference_on_cpu():
+        with contextlib.redirect_stdout(io.StringIO()):
+            import avse_model_final as ref_mod
+        for name, (b, t, w, fft, hpf) in CONFIGS.items():
+            n_bins = fft // 2 + 1
+            t_a = hpf * t
+            stft_shape = [b, 2, t_a, n_bins]
+            frame_shape = [b, 1, t, w, w]
+            with contextlib.redirect_stdout(io.StringIO()):
+                torch.manual_seed(0)
+                ref = ref_mod.AV_Fusion_Model_Frames(stft_shape, frame_shape, hpf)
+            twin = orc.AVFusionFramesRef(stft_shape, frame_shape, hpf)
+            assert list(ref.state_dict().keys()) == list(twin.state_dict().keys()), "state_dict keys differ"
+            for k, v in ref.state_dict().items():
+                assert v.shape == twin.state_dict()[k].shape, k
+            ref.load_state_dict(orc.seeded_state_dict(twin, SEED), strict=True)
+            orc.load_seeded(twin, SEED)
+            batch = orc.synthetic_batch(b, t, w, t_a, n_bins, hpf, SEED + 1)
+            got_ref = run(ref, *batch)
+            got_twin = run(twin, *batch)
+            for k in got_ref:
+                if got_ref[k].dtype.kind in "US":
+                    assert (got_ref[k] == got_twin[k]).all(), k
+                else:
+                    np.testing.assert_allclose(got_twin[k], got_ref[k], rtol=2e-5, atol=1e-6, err_msg=f"{name}:{k}")
+            meta = dict(batch=b, frames=t, width=w, fft_len=fft, hops_per_frame=hpf, seed=SEED,
+                        lr=LR, loss_coeff=LOSS_COEFF)
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"avse_{name}.npz"),
+                                **got_ref, **{f"meta_{k}": np.array(v) for k, v in meta.items()})
+            print(f"[golden] {name}: loss={got_ref['loss']:.8f} params={len(got_ref['param_names'])} "
+                  f"oracle==reference OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the DINO ViT-S/8 attention-frame extractor.
+
+Follows the reference's call sites
+  video_attention.py:106-114  vits.vit_small(patch_size=8, num_classes=0), frozen, eval
+  video_attention.py:38-57    per frame: crop to a multiple of 8, get_last_selfattention -> [1,6,N+1,N+1],
+                              keep the CLS row without its own column: attentions[0,:,0,1:]
+  video_attention.py:80-96    reshape [6,h,w], nearest x8 upsample, sum heads, divide by the frame max
+  av_dataset.py:323-333       optional temporal diff, divide by the clip max, permute to [1,T,H,W]
+(the sort/cumsum/threshold block at video_attention.py:59-78 never reaches the output).
+
+PARITY UNPINNED: `dino/` is an empty un-vendored git submodule of the reference
+(.gitmodules:1-3, no pinned commit) and its weights are fetched by URL
+(video_attention.py:152-154), unavailable offline.  The network below restates the
+published facebookresearch/dino `VisionTransformer` (vit_small: dim 384, depth 12,
+6 heads, MLP x4, qkv bias, pre-LN blocks with LayerNorm eps 1e-6, exact-erf GELU,
+Conv2d(3,384,k=8,s=8) patch embed, CLS token, learned 785x384 position embedding,
+bicubic-interpolated for inputs other than 224^2) with the same state_dict keys;
+tests cross-check it against `transformers.ViTModel` built from a local config.
+"""
+import math
+import zlib
+
+import torch
+import torch.nn.functional as F
+
+DIM, DEPTH, HEADS, MLP, PATCH = 384, 12, 6, 1536, 8
+LN_EPS = 1e-6
+
+
+def vit_param_shapes(img_size=224):
+    n = (img_size // PATCH) ** 2
+    sh = {"cls_token": (1, 1, DIM), "pos_embed": (1, n + 1, DIM),
+          "patch_embed.proj.weight": (DIM, 3, PATCH, PATCH), "patch_embed.proj.bias": (DIM,),
+          "norm.weight": (DIM,), "norm.bias": (DIM,)}
+    for i in range(DEPTH):
+        p = f"blocks.{i}."
+        sh.update({p + "norm1.weight": (DIM,), p + "norm1.bias": (DIM,),
+                   p + "attn.qkv.weight": (3 * DIM, DIM), p + "attn.qkv.bias": (3 * DIM,),
+                   p + "attn.proj.weight": (DIM, DIM), p + "attn.proj.bias": (DIM,),
+                   p + "norm2.weight": (DIM,), p + "norm2.bias": (DIM,),
+                   p + "mlp.fc1.weight": (MLP, DIM), p + "mlp.fc1.bias": (MLP,),
+                   p + "mlp.fc2.weight": (DIM, MLP), p + "mlp.fc2.bias": (DIM,)})
+    return sh
+
+
+def seeded_vit_state(seed, img_size=224):
+    """Random-but-reproducible weights with trained-network-like scales (no DINO checkpoint exists offline)."""
+    out = {}
+    for k, shape in vit_param_shapes(img_size).items():
+        g = torch.Generator(device="cpu")
+        g.manual_seed((zlib.crc32(k.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        r = torch.randn(shape, generator=g)
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k == "norm.weight":
+            t = 1.0 + 0.1 * r
+        elif k.endswith(".bias"):
+            t = 0.05 * r
+        elif k in ("cls_token", "pos_embed"):
+            t = 0.2 * r
+        elif k == "patch_embed.proj.weight":
+            t = r * (1.0 / math.sqrt(3 * PATCH * PATCH))
+        elif "attn.qkv.weight" in k:
+            t = r * (1.6 / math.sqrt(DIM))          # sharper-than-init logits so softmax is not flat
+        else:
+            t = r * (1.0 / math.sqrt(shape[1]))
+        out[k] = t.float()
+    return out
+
+
+def interpolate_pos_embed(pos_embed, h_tok, w_tok):
+    """Bicubic resize of the patch part of the position embedding (published DINO rule, incl. its +0.1)."""
+    n = pos_embed.shape[1] - 1
+    if n == h_tok * w_tok and h_tok == w_tok:
+        return pos_embed
+    side = int(math.sqrt(n))
+    patch = pos_embed[:, 1:].reshape(1, side, side, DIM).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, scale_factor=((h_tok + 0.1) / side, (w_tok + 0.1) / side), mode="bicubic")
+    assert patch.shape[-2] == h_tok and patch.shape[-1] == w_tok
+    patch = patch.permute(0, 2, 3, 1).reshape(1, -1, DIM)
+    return torch.cat([pos_embed[:, :1], patch], 1)
+
+
+def prepare_tokens(sd, frames):
+    b, _, h, w = frames.shape
+    x = F.conv2d(frames, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=PATCH)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([sd["cls_token"].expand(b, -1, -1), x], 1)
+    return x + interpolate_pos_embed(sd["pos_embed"], h // PATCH, w // PATCH)
+
+
+def block_forward(sd, i, x, return_attention=False):
+    p = f"blocks.{i}."
+    b, n, _ = x.shape
+    y = F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS)
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    qkv = qkv.reshape(b, n, 3, HEADS, DIM // HEADS).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = (q @ k.transpose(-2, -1)) * ((DIM // HEADS) ** -0.5)
+    att = att.softmax(-1)
+    if return_attention:
+        return att
+    y = (att @ v).transpose(1, 2).reshape(b, n, DIM)
+    x = x + F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    y = F.layer_norm(x, (DIM,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS)
+    y = F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def get_last_selfattention(sd, frames, return_hidden=False):
+    x = prepare_tokens(sd, frames)
+    hidden = [x]
+    for i in range(DEPTH - 1):
+        x = block_forward(sd, i, x)
+        hidden.append(x)
+    att = block_forward(sd, DEPTH - 1, x, return_attention=True)
+    return (att, hidden) if return_hidden else att
+
+
+def cls_attention(sd, frames):
+    """[B,3,H,W] -> CLS-row attention without the CLS column, [B, 6, N]."""
+    return get_last_selfattention(sd, frames)[:, :, 0, 1:]
+
+
+def attention_frames_from_cls(cls_att, h_tok, w_tok):
+    """video_attention.py:80-96 for a stack of frames: [T,6,N] -> [T,1,H,W], each frame /max."""
+    t = cls_att.shape[0]
+    a = cls_att.reshape(t, HEADS, h_tok, w_tok)
+    a = F.interpolate(a, scale_factor=PATCH, mode="nearest")
+    a = a.sum(1)
+    a = a * (1.0 / a.flatten(1).max(1).values)[:, None, None]
+    return a[:, None]
+
+
+def inference_ref(sd, frames):
+    """VideoAttention._inference: frames [T,3,H,W] -> [T,1,H,W] (H, W cropped to multiples of 8 are
+    written into a zero canvas of the original size, video_attention.py:39,43-47,96)."""
+    t, _, h, w = frames.shape
+    hc, wc = h - h % PATCH, w - w % PATCH
+    att = cls_attention(sd, frames[:, :, :hc, :wc])
+    out = torch.zeros(t, 1, h, w)
+    out[:, :, :hc, :wc] = attention_frames_from_cls(att, hc // PATCH, wc // PATCH)
+    return out
+
+
+def clip_normalise_ref(attn, attn_diff=False):
+    """av_dataset.py:323-333: attn [T,1,H,W] -> [1,T,H,W], divided by the clip max."""
+    if attn_diff:
+        attn = torch.cat([torch.zeros_like(attn[:1]), torch.diff(attn, dim=0)], 0)
+    attn = attn * (1.0 / attn.max())
+    return attn.permute(1, 0, 2, 3)
+
+
+def synthetic_frames(n, width, seed):
+    """U[0,1) RGB then ImageNet normalisation (av_dataset.py:110-111)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    x = torch.rand(n, 3, width, width, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]
+    return (x - mean) / std
