@@ -1,0 +1,7 @@
+"""maavss_amd -- MI355X-native (gfx950) implementation of the MAAVSS training hot path.
+
+Everything numerical runs in hand-written HIP kernels behind the C-ABI of include/maavss.h
+(libmaavss_hip.so); PyTorch-ROCm only owns device memory, streams and torch.distributed.
+"""
+from . import _lib  # noqa: F401
+from .stft import STFT, calc_hop_size  # noqa: F401

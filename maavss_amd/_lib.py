@@ -1,0 +1,93 @@
+"""ctypes binding of libmaavss_hip.so.
+
+The argument types of every entry point are derived from include/maavss.h (the single source of
+truth of the C-ABI), so the header, the library and this binding cannot drift apart silently.
+There is NO fallback: if the library is missing or an entry point fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "maavss.h")
+LIB_PATH = os.path.join(_PKG, "lib", "libmaavss_hip.so")
+
+_SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+            "float": ctypes.c_float, "double": ctypes.c_double, "uint32_t": ctypes.c_uint32}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argtype, argname)])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(maavss_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        argl = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argl.append((ctypes.c_void_p, a.split("*")[-1].strip()))
+                else:
+                    ty, nm = a.rsplit(" ", 1)
+                    ty = ty.replace("const ", "").strip()
+                    argl.append((_SCALARS[ty], nm))
+        protos[name] = (restype, argl)
+    return protos
+
+
+class MaavssError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.isfile(LIB_PATH):
+            raise MaavssError(
+                f"{LIB_PATH} not found: the HIP library is the product path and has no fallback. "
+                f"Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C maavss_amd/csrc`.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (restype, args) in self.protos.items():
+            fn = getattr(self.cdll, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = [t for t, _ in args]
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise MaavssError(f"{name} failed (status {rc}): {self.cdll.maavss_last_error().decode()}")
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def call(name, *args):
+    lib().call(name, *args)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MaavssError("maavss_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")

@@ -1,0 +1,88 @@
+// Shared device/host helpers for libmaavss_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define MAAVSS_OK 0
+#define MAAVSS_ERR_ARG 1
+#define MAAVSS_ERR_LAUNCH 2
+
+void maavss_set_error(const char* fmt, ...);
+
+#define MAAVSS_CHECK_ARG(cond, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      maavss_set_error(__VA_ARGS__);           \
+      return MAAVSS_ERR_ARG;                   \
+    }                                          \
+  } while (0)
+
+#define MAAVSS_LAUNCH_CHECK(name)                                              \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      maavss_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return MAAVSS_ERR_LAUNCH;                                                \
+    }                                                                          \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (compiler emits v_cvt_pk_bf16_f32)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10 counter RNG (Salmon et al. 2011) -> 4 x N(0,1) via Box-Muller.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t idx, float out[4]) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), 0x5A17u, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float u1 = ((float)(c[2 * p] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(c[2 * p + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float r = sqrtf(-2.0f * __logf(u1));
+    float s, co;
+    sincospif(2.0f * u2, &s, &co);
+    out[2 * p] = r * co;
+    out[2 * p + 1] = r * s;
+  }
+}

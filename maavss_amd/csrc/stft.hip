@@ -1,0 +1,147 @@
+// K17: audio STFT (+ noise) -- replaces AV_Dataset.stft / gen_stft_example / add_noise
+// (reference av_dataset.py:157-174, 217-220, 335-342).
+//
+// One wavefront per STFT frame: reflect-padded framing + (pre-scaled) periodic Hamming window are
+// applied while the frame is loaded into LDS, a radix-2 Stockham FFT runs in LDS (ping-pong
+// buffers, twiddles from an LDS table), and the one-sided bins are written straight into the
+// [B, 2, T_a, F] (re/im plane, frame, bin) layout the model consumes, together with the noisy
+// copy x = y + sigma * N(0,1).  HBM-bound: 4*L bytes in, 2 * 2*T_a*F*4 bytes out per clip.
+#include "common.h"
+
+
+template <int NFFT, int STFT_FPB>
+__global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
+    const float* __restrict__ audio, int64_t audio_stride, int length, const float* __restrict__ window, int hop,
+    int n_frames, int n_bins_out, int total_frames, float* __restrict__ y, float* __restrict__ x,
+    const float* __restrict__ noise, float sigma, uint64_t seed, float* __restrict__ clip_absmax) {
+  constexpr int LOG2N = NFFT == 256 ? 8 : (NFFT == 512 ? 9 : 10);
+  __shared__ float2 buf[2][STFT_FPB][NFFT];
+  __shared__ float2 tw[NFFT / 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int q = threadIdx.x; q < NFFT / 2; q += blockDim.x) {
+    float s, c;
+    sincospif(-2.0f * (float)q / (float)NFFT, &s, &c);
+    tw[q] = make_float2(c, s);
+  }
+  const int fid = blockIdx.x * STFT_FPB + wv;
+  const bool active = fid < total_frames;
+  const int b = active ? fid / n_frames : 0, t = active ? fid % n_frames : 0;
+  const float* a = audio + (int64_t)b * audio_stride;
+  for (int n = lane; n < NFFT; n += 64) {
+    int j = t * hop + n - NFFT / 2;
+    if (j < 0) j = -j;
+    if (j >= length) j = 2 * (length - 1) - j;
+    float v = active ? a[j] * window[n] : 0.f;
+    buf[0][wv][n] = make_float2(v, 0.f);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < LOG2N; ++s) {
+    const int p = 1 << s;
+    for (int i = lane; i < NFFT / 2; i += 64) {
+      const int k = i & (p - 1);
+      float2 u0 = buf[cur][wv][i];
+      float2 u1 = buf[cur][wv][i + NFFT / 2];
+      float2 w = tw[k * (NFFT / (2 * p))];
+      float2 v = make_float2(u1.x * w.x - u1.y * w.y, u1.x * w.y + u1.y * w.x);
+      const int j = ((i - k) << 1) + k;
+      buf[cur ^ 1][wv][j] = make_float2(u0.x + v.x, u0.y + v.y);
+      buf[cur ^ 1][wv][j + p] = make_float2(u0.x - v.x, u0.y - v.y);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (!active) return;
+  const int64_t plane = (int64_t)n_frames * n_bins_out;
+  float* yre = y + ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out;
+  float* yim = yre + plane;
+  float amax = 0.f;
+  for (int f = lane; f < n_bins_out; f += 64) {
+    float2 v = buf[cur][wv][f];
+    yre[f] = v.x;
+    yim[f] = v.y;
+    amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+    if (x != nullptr) {
+      const int64_t ore = ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out + f;
+      float nr, ni;
+      if (noise != nullptr) {
+        nr = noise[ore];
+        ni = noise[ore + plane];
+      } else {
+        float g[4];
+        philox_normal4(seed, (uint64_t)fid * n_bins_out + f, g);
+        nr = g[0];
+        ni = g[1];
+      }
+      x[ore] = v.x + sigma * nr;
+      x[ore + plane] = v.y + sigma * ni;
+    }
+  }
+  if (clip_absmax != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax((unsigned int*)(clip_absmax + b), __float_as_uint(amax));  // amax >= 0
+  }
+}
+
+// normalize_output_fft path (av_dataset.py:339-341): y *= 1/(max|y| + 1e-7) per clip, then x = y + sigma*N.
+__global__ void stft_normalise_kernel(float* __restrict__ y, float* __restrict__ x, const float* __restrict__ noise,
+                                      const float* __restrict__ clip_absmax, int64_t per_clip, int64_t total,
+                                      int n_frames, int n_bins_out, float sigma, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per_clip;
+    const float s = 1.0f / (clip_absmax[b] + 1e-7f);
+    const float v = y[i] * s;
+    y[i] = v;
+    if (x != nullptr) {
+      float nz;
+      if (noise != nullptr) {
+        nz = noise[i];
+      } else {
+        const int64_t r = i - b * per_clip;
+        const int64_t plane = (int64_t)n_frames * n_bins_out;
+        const int pl = (int)(r / plane);
+        const int64_t tf = r - pl * plane;  // t * n_bins + f
+        float g[4];
+        philox_normal4(seed, (uint64_t)(b * n_frames) * n_bins_out + tf, g);
+        nz = g[pl];
+      }
+      x[i] = v + sigma * nz;
+    }
+  }
+}
+
+extern "C" int maavss_stft_fwd(const float* audio, int64_t batch, int64_t length, int64_t audio_stride,
+                               const float* window, int n_fft, int hop, int n_frames, int n_bins_out, float* y,
+                               float* x, const float* noise, float sigma, uint64_t seed, float* clip_absmax,
+                               void* stream) {
+  MAAVSS_CHECK_ARG(n_fft == 256 || n_fft == 512 || n_fft == 1024, "stft: n_fft must be 256, 512 or 1024 (got %d)", n_fft);
+  MAAVSS_CHECK_ARG(audio && window && y, "stft: null pointer");
+  MAAVSS_CHECK_ARG(batch > 0 && hop > 0 && n_frames > 0, "stft: empty problem");
+  MAAVSS_CHECK_ARG(n_bins_out >= 1 && n_bins_out <= n_fft / 2 + 1, "stft: n_bins_out out of range");
+  MAAVSS_CHECK_ARG(length > n_fft / 2, "stft: reflect padding needs length > n_fft/2");
+  MAAVSS_CHECK_ARG((int64_t)(n_frames - 1) * hop + n_fft / 2 - 1 < 2 * length - 1, "stft: frames run past the reflected signal");
+  const int total = (int)(batch * n_frames);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N, FPB)                                                                                         \
+  hipLaunchKernelGGL((stft_kernel<N, FPB>), dim3(cdiv(total, FPB)), dim3(64 * FPB), 0, st, audio, audio_stride, \
+                     (int)length, window, hop, n_frames, n_bins_out, total, y, x, noise, sigma, seed, clip_absmax)
+  if (n_fft == 256) LAUNCH(256, 4);
+  else if (n_fft == 512) LAUNCH(512, 4);
+  else LAUNCH(1024, 2);
+#undef LAUNCH
+  MAAVSS_LAUNCH_CHECK("stft_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_stft_normalise(float* y, float* x, const float* noise, const float* clip_absmax, int64_t batch,
+                                     int n_frames, int n_bins_out, float sigma, uint64_t seed, void* stream) {
+  MAAVSS_CHECK_ARG(y && clip_absmax, "stft_normalise: null pointer");
+  const int64_t per_clip = 2LL * n_frames * n_bins_out, total = per_clip * batch;
+  int grid = cdiv(total, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(stft_normalise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, noise, clip_absmax,
+                     per_clip, total, n_frames, n_bins_out, sigma, seed);
+  MAAVSS_LAUNCH_CHECK("stft_normalise_kernel");
+  return MAAVSS_OK;
+}

@@ -1,0 +1,55 @@
+"""GPU parity: K17 STFT(+noise) kernel through the C-ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fft_len,frames", [(512, 8), (256, 8), (1024, 32), (512, 16)])
+def test_stft_matches_oracle(fft_len, frames):
+    import maavss_amd
+    from oracle import stft_ref_cpu as sref
+    hop, length, t_a = maavss_amd.calc_hop_size(frames, 8, 30, 16000)
+    audio = sref.synthetic_audio(3, length, 5)
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(3, 2, t_a, fft_len // 2 + 1, generator=g)
+    st = maavss_amd.STFT(fft_len, hop, noise_std=0.1, device="cuda")
+    x, y = st(audio.cuda(), noise=noise.cuda())
+    xr, yr = sref.gen_stft_example_ref(audio, fft_len, hop, 0.1, noise)
+    assert y.shape == (3, 2, t_a, fft_len // 2 + 1)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=0, atol=5e-6)   # fp32 tolerance, |y| <= ~0.5
+    np.testing.assert_allclose(x.cpu().numpy(), xr.numpy(), rtol=0, atol=5e-6)
+
+
+def test_stft_trim_and_normalise_output():
+    import maavss_amd
+    from oracle import stft_ref_cpu as sref
+    hop, length, t_a = maavss_amd.calc_hop_size(8, 8, 30, 16000)
+    audio = sref.synthetic_audio(2, length, 6)
+    noise = torch.randn(2, 2, t_a, 257, generator=torch.Generator().manual_seed(1))
+    st = maavss_amd.STFT(512, hop, noise_std=0.1, normalize_output_fft=True, device="cuda")
+    x, y = st(audio.cuda(), noise=noise.cuda())
+    xr, yr = sref.gen_stft_example_ref(audio, 512, hop, 0.1, noise, normalize_output=True)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(x.cpu().numpy(), xr.numpy(), rtol=0, atol=2e-5)
+    st2 = maavss_amd.STFT(512, hop, trim_stft_end=True, device="cuda")
+    _, y2 = st2(audio.cuda(), want_x=False)
+    np.testing.assert_allclose(y2.cpu().numpy(), sref.stft_ref(audio, 512, hop, trim_stft_end=True).numpy(), atol=5e-6)
+
+
+def test_stft_device_noise_statistics():
+    """In-kernel Philox noise: x - y must be N(0, sigma^2) (no reference RNG stream to match)."""
+    import maavss_amd
+    from oracle import stft_ref_cpu as sref
+    hop, length, t_a = maavss_amd.calc_hop_size(16, 8, 30, 16000)
+    audio = sref.synthetic_audio(8, length, 7).cuda()
+    st = maavss_amd.STFT(512, hop, noise_std=0.1, device="cuda")
+    x, y = st(audio, seed=123)
+    d = (x - y).flatten().double() / 0.1
+    assert abs(d.mean().item()) < 5e-3 and abs(d.std().item() - 1) < 5e-3
+    assert abs((d ** 3).mean().item()) < 2e-2 and abs((d ** 4).mean().item() - 3) < 5e-2
+    x2, _ = st(audio, seed=124)
+    assert (x2 - x).abs().max().item() > 0.1      # different seed, different draw
+    x3, _ = st(audio, seed=123)
+    assert torch.equal(x3, x)                     # same seed, same draw
