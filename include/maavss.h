@@ -42,6 +42,90 @@ int maavss_stft_fwd(const float* audio, int64_t batch, int64_t length, int64_t a
 int maavss_stft_normalise(float* y, float* x, const float* noise, const float* clip_absmax, int64_t batch,
                           int n_frames, int n_bins_out, float sigma, uint64_t seed, void* stream);
 
+/* ---- generic f32 GEMM on MFMA -----------------------------------------------------------------
+ * C[M,N] = act(alpha * op(A)[M,K] . op(B)[N,K]^T) (+ C when beta = 1).  Replaces the nn.Linear forwards
+ * of avse_model_final.py:141-146,203-213,244-249,264-268, the LSTM input projection (:132,242) and the
+ * gradients autograd derives from them.  transA=0: A[m*lda+k], 1: A[k*lda+m]; transB=0: B[n*ldb+k]
+ * (torch Linear weight layout), 1: B[k*ldb+n]; transC=0: C[m*ldc+n], 1: C[n*ldc+m].
+ * act: 0 none, 1 tanh, 2 sigmoid.  split_k: 0 = auto, n>1 = split K over n blocks (f32 atomics). */
+int maavss_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                    int64_t ldc, int transC, int64_t M, int64_t N, int64_t K, float alpha, int beta, int act,
+                    int split_k, int precise, void* stream);
+
+/* ---- K7/K8 Conv3d(k=(3,5,5), stride 1, pad (1,p,p), bias=False) -- avse_model_final.py:34,39,44,49,54 ----
+ * Activations channels-last [B][T][H][W][C] f32.  Weights in the reference layout [Co][Ci][3][5][5].
+ * maavss_conv3d_kp(c_in): padded K of the re-laid weight image; prep writes wt[3][n][KP] in bf16 (precise=0)
+ * or f32 (precise=1): mode 0 = forward (n=Co), mode 1 = input gradient (n=Ci; flipped taps, use pad 4-p).
+ * igemm: y[B][T][Ho][Wo][c_out], Ho = H+2*pad-4; stat_partials (nullable) [grid blocks][2][c_out] receives
+ * per-block (sum, sum^2) for BatchNorm, grid blocks = ceil(Wo/16)*ceil(Ho/16)*B*T.
+ * wgrad: dw[Co][Ci][3][5][5] (+= when beta=1); ws of maavss_conv3d_wgrad_ws_bytes(c_in,c_out,nchunk) bytes. */
+int maavss_conv3d_kp(int c_in);
+int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, int c_in, int mode, int precise, void* stream);
+int maavss_conv3d_igemm(const float* x, const void* wt, float* y, float* stat_partials, int B, int T, int H, int W,
+                        int c_in, int c_out, int pad, int precise, void* stream);
+int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk);
+int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
+                        int c_in, int c_out, int pad, int beta, int precise, void* stream);
+/* first layer (C_in = 1, pad 2): x [B][T][H][W], w [16][1][3][5][5], w16_ws 1200 floats scratch,
+ * y [B][T][H][W][16]; stat_partials as above; wgrad ws = nchunk*1200 floats. */
+int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B, int T,
+                         int H, int W, void* stream);
+int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
+                           int W, int beta, void* stream);
+
+/* ---- K9 BatchNorm (train mode) + MaxPool(1,p,p) + LeakyReLU / BatchNorm2d + Tanh -----------------
+ * avse_model_final.py:35-37,...,55-57 (pool before activation) and :103-104 (pool = 1, act = 1).
+ * y channels-last [B*T][H][W][C]; the pooled output (and its gradient) are addressed with element strides
+ * b*os_b + t*os_t + (py*Wp+px)*os_p + c*os_c so the last stage can write the [B,16,T,S] / LSTM-sequence
+ * layout directly (avse_model_final.py:58,239-240).  act: 0 LeakyReLU(0.01), 1 Tanh.
+ * bn_finalize: count = B*T*H*W; updates running stats with `momentum` and the unbiased variance and
+ * increments num_batches_tracked (int64) like torch.nn.BatchNorm (pointers nullable).
+ * bwd ws: (2*C*nblk + 3*C) floats, nblk = maavss_bn_stats_nblk(B*T*Hp*Wp). */
+int maavss_bn_stats_nblk(int64_t rows);
+int maavss_bn_stats(const float* y, float* partials, int64_t rows, int C, void* stream);
+int maavss_bn_finalize(const float* partials, int nblk, int C, double count, float eps, float momentum, float* mean,
+                       float* invstd, float* running_mean, float* running_var, void* num_batches_tracked,
+                       void* stream);
+int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C, int pool,
+                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
+                           const float* mean, const float* invstd, const float* gamma, float* dy, float* dgamma,
+                           float* dbeta, int accumulate, float* ws, int B, int T, int H, int W, int C, int pool,
+                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+
+/* ---- K10 Conv2d(k=(3,9), stride (sh,sw), pad (1,pw), bias=False) -- avse_model_final.py:98-102 ----
+ * in_layout 0: x NCHW [B][Ci][H][W] (network input), 1: NHWC; y/dy NHWC [B][Ho][Wo][Co]; w [Co][Ci][3][9].
+ * wgrad ws: maavss_conv2d_wgrad_nchunk(B,Ho,Wo,Ci,Co) * Co*Ci*27 floats. */
+int maavss_conv2d_fwd(const float* x, const float* w, float* y, int B, int Ci, int H, int W, int Co, int sh, int sw,
+                      int pw, int in_layout, void* stream);
+int maavss_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci, int H, int W, int Co, int sh,
+                        int sw, int pw, void* stream);
+int maavss_conv2d_wgrad_nchunk(int B, int Ho, int Wo, int Ci, int Co);
+int maavss_conv2d_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Ci, int H, int W, int Co,
+                        int sh, int sw, int pw, int in_layout, int beta, void* stream);
+
+/* ---- K12 bidirectional LSTM recurrence (hidden 256, no bias) -- avse_model_final.py:132-133,242 ----
+ * gx [B][L][2][4][256] = X.W_ih^T (both directions, gate order i,f,g,o); av [B][L][512]; hp [B][L][2][256];
+ * gs [B][L][2][4][256]; cs [B][L][2][256]; bwd: dav [B][L][512] -> dgx (same shape as gx), dc scratch [2][B][256]. */
+int maavss_lstm_fwd(const float* gx, const float* whh_f, const float* whh_b, float* av, float* hp, float* gs,
+                    float* cs, int B, int L, void* stream);
+int maavss_lstm_bwd(const float* dav, const float* whh_f, const float* whh_b, const float* gs, const float* cs,
+                    float* dgx, float* dc, int B, int L, void* stream);
+
+/* ---- K15/K16 loss, activation backward, Adam ---------------------------------------------------
+ * act_bwd: dz = dout * act'(out), act 1 tanh / 2 sigmoid (avse_model_final.py:246-249,264-268).
+ * mse_pair: losses[0..2] = a_loss, v_loss, (a_loss + coeff*v_loss)*inv_num_seq and (nullable) the gradients
+ * of losses[2] w.r.t. the predictions (train_avse_frames.py:166-170); ws = 1024 floats.
+ * adam_step: torch.optim.Adam semantics (train_avse_frames.py:92,180) on flat 16-byte-aligned buffers;
+ * `step` is the 1-based step count, grad_scale multiplies g (1/world_size for data parallel). */
+int maavss_act_bwd(const float* dout, const float* out, float* dz, int64_t n, int act, void* stream);
+int maavss_mse_pair(const float* a_pred, const float* a_tgt, int64_t na, const float* v_pred, const float* v_tgt,
+                    int64_t nv, float coeff, float inv_num_seq, float* d_a, float* d_v, float* losses, float* ws,
+                    void* stream);
+int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, int64_t step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,9 +23,9 @@ def parse_header(path=HEADER):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(maavss_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(maavss_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
         argl = []
         if args and args != "void":
             for a in args.split(","):
@@ -62,6 +62,10 @@ class _Lib:
         if rc != 0:
             raise MaavssError(f"{name} failed (status {rc}): {self.cdll.maavss_last_error().decode()}")
 
+    def query(self, name, *args):
+        """Entry points that return a size/count instead of a status."""
+        return getattr(self.cdll, name)(*args)
+
 
 _lib = None
 
@@ -75,6 +79,10 @@ def lib():
 
 def call(name, *args):
     lib().call(name, *args)
+
+
+def query(name, *args):
+    return lib().query(name, *args)
 
 
 def ptr(t):

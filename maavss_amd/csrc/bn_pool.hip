@@ -1,0 +1,263 @@
+// K9/K10 (normalisation part): train-mode BatchNorm + MaxPool(1,p,p) + LeakyReLU(0.01)  (visual encoder,
+// reference avse_model_final.py:35-37 ... 55-57: pool BEFORE the activation) and BatchNorm2d + Tanh (STFT
+// encoder, :103-104; p = 1).  All tensors channels-last f32; HBM-bound elementwise/reduction kernels.
+//
+//   bn_stats          per-channel (sum, sum^2) partials of a [M][C] tensor (conv kernels can also emit them)
+//   bn_finalize       partials -> mean / invstd (biased var, eps) + running stats update (momentum, unbiased var)
+//   bn_pool_act_fwd   out = act(maxpool_p(gamma * (y - mean) * invstd + beta)), argmax index per window
+//   bn_pool_act_bwd_reduce   g = dout * act'(out) routed to the argmax; per-channel partials of (sum g, sum g*xhat)
+//   bn_bwd_finalize   partials -> dgamma, dbeta, and the three per-channel constants of the dx formula
+//   bn_pool_act_bwd_dx       dy = gamma*invstd * (g_at_argmax - mean(g) - xhat * mean(g*xhat))   (dense, full res)
+#include "common.h"
+
+#define ACT_LEAKY 0
+#define ACT_TANH 1
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partials,
+                                                       int64_t M, int C, int rows_per_block) {
+  // thread -> channel c = tid % C, row phase tid / C; C is a power of two <= 64
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x, c = tid % C, ph = tid / C, nph = 256 / C;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t r = r0 + ph; r < r1; r += nph) {
+    const float v = y[r * C + c];
+    s1 += v;
+    s2 += v * v;
+  }
+  red[0][tid] = s1;
+  red[1][tid] = s2;
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f, b = 0.f;
+    for (int p = 0; p < nph; ++p) { a += red[0][p * C + tid]; b += red[1][p * C + tid]; }
+    partials[(int64_t)blockIdx.x * 2 * C + tid] = a;
+    partials[(int64_t)blockIdx.x * 2 * C + C + tid] = b;
+  }
+}
+
+// one block; thread c reduces channel c over nblk partials in double.
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double count, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches_tracked) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s1 += (double)partials[(int64_t)b * 2 * C + c];
+      s2 += (double)partials[(int64_t)b * 2 * C + C + c];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+}
+
+struct PoolGeom {
+  int BT, T, H, W, C, p, Hp, Wp;
+  int64_t osB, osT, osP, osC;  // element strides of the pooled output / its gradient
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) { return act == ACT_TANH ? tanhf(v) : (v > 0.f ? v : 0.01f * v); }
+__device__ __forceinline__ float act_bwd_from_out(float out, int act) {
+  return act == ACT_TANH ? 1.f - out * out : (out > 0.f ? 1.f : 0.01f);
+}
+
+__global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ out, unsigned char* __restrict__ argmax,
+                                                              PoolGeom g, int act) {
+  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * g.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % g.C);
+    const int64_t pos = i / g.C;
+    const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    float best = -INFINITY;
+    int bi = 0;
+    const float* yp = y + (((int64_t)bt * g.H + (int64_t)py * g.p) * g.W + (int64_t)px * g.p) * g.C + c;
+    for (int dy = 0; dy < g.p; ++dy)
+      for (int dx = 0; dx < g.p; ++dx) {
+        const float v = yp[((int64_t)dy * g.W + dx) * g.C] * sc + sh;
+        if (v > best || (v != v && best == best)) { best = v; bi = dy * g.p + dx; }
+      }
+    const int b = bt / g.T, t = bt % g.T;
+    out[b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC] = act_fwd(best, act);
+    if (argmax != nullptr) argmax[i] = (unsigned char)bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
+    const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ partials, PoolGeom g, int act, int64_t rows_per_block) {
+  // rows = pooled positions; thread -> (channel, row phase)
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x, C = g.C, c = tid % C, ph = tid / C, nph = 256 / C;
+  const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const float mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t pos = r0 + ph; pos < r1; pos += nph) {
+    const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
+    const int b = bt / g.T, t = bt % g.T;
+    const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+    const float gg = dout[oi] * act_bwd_from_out(out[oi], act);
+    const int bi = argmax != nullptr ? argmax[pos * C + c] : 0;
+    const int iy = py * g.p + bi / g.p, ix = px * g.p + bi % g.p;
+    const float xh = (y[(((int64_t)bt * g.H + iy) * g.W + ix) * C + c] - mu) * is;
+    s1 += gg;
+    s2 += gg * xh;
+  }
+  red[0][tid] = s1;
+  red[1][tid] = s2;
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f, b2 = 0.f;
+    for (int p = 0; p < nph; ++p) { a += red[0][p * C + tid]; b2 += red[1][p * C + tid]; }
+    partials[(int64_t)blockIdx.x * 2 * C + tid] = a;
+    partials[(int64_t)blockIdx.x * 2 * C + C + tid] = b2;
+  }
+}
+
+// coef[0][c] = gamma*invstd, coef[1][c] = sum(g)/N, coef[2][c] = sum(g*xhat)/N
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ coef) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)partials[(int64_t)b * 2 * C + c];
+    s2 += (double)partials[(int64_t)b * 2 * C + C + c];
+  }
+  if (dgamma != nullptr) {
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  }
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = (float)(s1 / count);
+  coef[2 * C + c] = (float)(s2 / count);
+}
+
+__global__ __launch_bounds__(256) void bn_pool_act_bwd_dx_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
+    const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ coef, float* __restrict__ dy, PoolGeom g, int act) {
+  const int C = g.C;
+  const int64_t total = (int64_t)g.BT * g.H * g.W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t pos = i / C;
+    const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), bt = (int)(pos / ((int64_t)g.W * g.H));
+    const int py = iy / g.p, px = ix / g.p;
+    float gg = 0.f;
+    if (py < g.Hp && px < g.Wp) {
+      const int64_t ppos = ((int64_t)bt * g.Hp + py) * g.Wp + px;
+      const int bi = argmax != nullptr ? argmax[ppos * C + c] : 0;
+      if (bi == (iy - py * g.p) * g.p + (ix - px * g.p)) {
+        const int b = bt / g.T, t = bt % g.T;
+        const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+        gg = dout[oi] * act_bwd_from_out(out[oi], act);
+      }
+    }
+    const float xh = (y[i] - mean[c]) * invstd[c];
+    dy[i] = coef[c] * (gg - coef[C + c] - xh * coef[2 * C + c]);
+  }
+}
+
+static int check_geom(const char* who, int B, int T, int H, int W, int C, int p) {
+  MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "%s: empty tensor", who);
+  MAAVSS_CHECK_ARG(C >= 1 && C <= 64 && (C & (C - 1)) == 0, "%s: C must be a power of two <= 64 (got %d)", who, C);
+  MAAVSS_CHECK_ARG(p >= 1 && p <= 3, "%s: pool must be 1, 2 or 3", who);
+  MAAVSS_CHECK_ARG(H / p > 0 && W / p > 0, "%s: pooled size is zero", who);
+  return MAAVSS_OK;
+}
+
+static PoolGeom make_geom(int B, int T, int H, int W, int C, int p, int64_t osB, int64_t osT, int64_t osP, int64_t osC) {
+  PoolGeom g;
+  g.BT = B * T; g.T = T; g.H = H; g.W = W; g.C = C; g.p = p; g.Hp = H / p; g.Wp = W / p;
+  g.osB = osB; g.osT = osT; g.osP = osP; g.osC = osC;
+  return g;
+}
+
+extern "C" int maavss_bn_stats_nblk(int64_t rows) {
+  int64_t n = (rows + 1023) / 1024;
+  if (n > 2048) n = 2048;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int maavss_bn_stats(const float* y, float* partials, int64_t rows, int C, void* stream) {
+  MAAVSS_CHECK_ARG(y && partials && rows > 0, "bn_stats: bad arguments");
+  MAAVSS_CHECK_ARG(C >= 1 && C <= 64 && (C & (C - 1)) == 0, "bn_stats: C must be a power of two <= 64");
+  const int nblk = maavss_bn_stats_nblk(rows);
+  const int rpb = cdiv(rows, nblk);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, partials, rows, C, rpb);
+  MAAVSS_LAUNCH_CHECK("bn_stats_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_bn_finalize(const float* partials, int nblk, int C, double count, float eps, float momentum,
+                                  float* mean, float* invstd, float* running_mean, float* running_var,
+                                  void* num_batches_tracked, void* stream) {
+  MAAVSS_CHECK_ARG(partials && mean && invstd && nblk > 0 && C > 0 && C <= 64, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, C, count, eps, momentum,
+                     mean, invstd, running_mean, running_var, (long long*)num_batches_tracked);
+  MAAVSS_LAUNCH_CHECK("bn_finalize_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C,
+                                      int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
+                                      void* stream) {
+  MAAVSS_CHECK_ARG(y && mean && invstd && gamma && beta && out, "bn_pool_act_fwd: null pointer");
+  if (int rc = check_geom("bn_pool_act_fwd", B, T, H, W, C, pool)) return rc;
+  MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_fwd: argmax buffer required when pool > 1");
+  PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
+  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C;
+  hipLaunchKernelGGL(bn_pool_act_fwd_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, g, act);
+  MAAVSS_LAUNCH_CHECK("bn_pool_act_fwd_kernel");
+  return MAAVSS_OK;
+}
+
+// ws: at least (2*C*nblk + 3*C) floats with nblk = maavss_bn_stats_nblk(B*T*Hp*Wp); coef = ws + 2*C*nblk
+extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
+                                      const float* mean, const float* invstd, const float* gamma, float* dy,
+                                      float* dgamma, float* dbeta, int accumulate, float* ws, int B, int T, int H, int W,
+                                      int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
+                                      void* stream) {
+  MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && dy && ws, "bn_pool_act_bwd: null pointer");
+  if (int rc = check_geom("bn_pool_act_bwd", B, T, H, W, C, pool)) return rc;
+  MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_bwd: argmax buffer required when pool > 1");
+  hipStream_t st = (hipStream_t)stream;
+  PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
+  const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
+  const int nblk = maavss_bn_stats_nblk(rows);
+  float* coef = ws + (int64_t)2 * C * nblk;
+  hipLaunchKernelGGL(bn_pool_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dout, out, (const unsigned char*)argmax,
+                     y, mean, invstd, ws, g, act, (int64_t)cdiv(rows, nblk));
+  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_reduce_kernel");
+  const double count = (double)g.BT * H * W;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, ws, nblk, C, count, gamma, invstd, dgamma, dbeta,
+                     accumulate, coef);
+  MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+  const int64_t total = (int64_t)g.BT * H * W * C;
+  hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
+                     (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);
+  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");
+  return MAAVSS_OK;
+}

@@ -1,0 +1,169 @@
+// K10 (convolution part): the STFT encoder's Conv2d(k=(3,9), stride (sh,sw) in {1,2}^2, pad (1,pw), bias=False)
+// layers (reference avse_model_final.py:98-102), forward / input gradient / weight gradient.
+// 2 -> 4 -> 8 -> 16 (-> 16) channels on at most [128 x 257] maps: a few MFLOP per clip, so these are plain
+// direct kernels (one thread per output element, inputs through L1/L2), HBM/latency-bound.
+// Input layout 0 = NCHW (the network input x_stft [B,2,T_a,F]) or 1 = NHWC; outputs are NHWC.
+// Weights stay in the reference layout [Co][Ci][3][9].
+#include "common.h"
+
+struct C2Geom {
+  int B, Ci, H, W, Co, Ho, Wo, sh, sw, pw, in_layout;
+};
+
+__device__ __forceinline__ int64_t in_index(const C2Geom& g, int b, int ci, int iy, int ix) {
+  return g.in_layout ? (((int64_t)b * g.H + iy) * g.W + ix) * g.Ci + ci : (((int64_t)b * g.Ci + ci) * g.H + iy) * g.W + ix;
+}
+
+__global__ __launch_bounds__(256) void conv2d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, C2Geom g) {
+  const int64_t total = (int64_t)g.B * g.Ho * g.Wo * g.Co;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i % g.Co);
+    const int64_t pos = i / g.Co;
+    const int ox = (int)(pos % g.Wo), oy = (int)((pos / g.Wo) % g.Ho), b = (int)(pos / ((int64_t)g.Wo * g.Ho));
+    float acc = 0.f;
+    for (int ci = 0; ci < g.Ci; ++ci)
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy * g.sh + kh - 1;
+        if (iy < 0 || iy >= g.H) continue;
+        const float* wp = w + (((int64_t)co * g.Ci + ci) * 3 + kh) * 9;
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) {
+          const int ix = ox * g.sw + kw - g.pw;
+          if (ix >= 0 && ix < g.W) acc = fmaf(x[in_index(g, b, ci, iy, ix)], wp[kw], acc);
+        }
+      }
+    y[i] = acc;
+  }
+}
+
+// dx (NHWC) [B][H][W][Ci]
+__global__ __launch_bounds__(256) void conv2d_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           float* __restrict__ dx, C2Geom g) {
+  const int64_t total = (int64_t)g.B * g.H * g.W * g.Ci;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(i % g.Ci);
+    const int64_t pos = i / g.Ci;
+    const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), b = (int)(pos / ((int64_t)g.W * g.H));
+    float acc = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = iy + 1 - kh;
+      if (ty < 0 || ty % g.sh != 0) continue;
+      const int oy = ty / g.sh;
+      if (oy >= g.Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 9; ++kw) {
+        const int tx = ix + g.pw - kw;
+        if (tx < 0 || tx % g.sw != 0) continue;
+        const int ox = tx / g.sw;
+        if (ox >= g.Wo) continue;
+        const float* dp = dy + (((int64_t)b * g.Ho + oy) * g.Wo + ox) * g.Co;
+        for (int co = 0; co < g.Co; ++co) acc = fmaf(dp[co], w[(((int64_t)co * g.Ci + ci) * 3 + kh) * 9 + kw], acc);
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// partials[chunk][co][ci][27]; block = (co*Ci+ci, chunk)
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ partials, C2Geom g, int64_t pos_per_chunk) {
+  __shared__ float red[4][27];
+  const int pair = blockIdx.x, co = pair / g.Ci, ci = pair % g.Ci;
+  const int64_t npos = (int64_t)g.B * g.Ho * g.Wo;
+  const int64_t p0 = (int64_t)blockIdx.y * pos_per_chunk, p1 = min(npos, p0 + pos_per_chunk);
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  for (int64_t pos = p0 + threadIdx.x; pos < p1; pos += 256) {
+    const int ox = (int)(pos % g.Wo), oy = (int)((pos / g.Wo) % g.Ho), b = (int)(pos / ((int64_t)g.Wo * g.Ho));
+    const float d = dy[pos * g.Co + co];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy * g.sh + kh - 1;
+      const bool oky = iy >= 0 && iy < g.H;
+#pragma unroll
+      for (int kw = 0; kw < 9; ++kw) {
+        const int ix = ox * g.sw + kw - g.pw;
+        if (oky && ix >= 0 && ix < g.W) acc[kh * 9 + kw] = fmaf(d, x[in_index(g, b, ci, iy, ix)], acc[kh * 9 + kw]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    partials[((int64_t)blockIdx.y * gridDim.x + pair) * 27 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void conv2d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int n, int nchunk, int beta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * n + i];
+  dw[i] = beta ? dw[i] + s : s;
+}
+
+static int make_c2geom(const char* who, C2Geom* g, int B, int Ci, int H, int W, int Co, int sh, int sw, int pw, int in_layout) {
+  MAAVSS_CHECK_ARG(B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, "%s: empty problem", who);
+  MAAVSS_CHECK_ARG((sh == 1 || sh == 2) && (sw == 1 || sw == 2), "%s: stride must be 1 or 2", who);
+  MAAVSS_CHECK_ARG(pw >= 0 && pw <= 8, "%s: bad padding", who);
+  g->B = B; g->Ci = Ci; g->H = H; g->W = W; g->Co = Co; g->sh = sh; g->sw = sw; g->pw = pw; g->in_layout = in_layout;
+  g->Ho = (H + 2 - 3) / sh + 1;
+  g->Wo = (W + 2 * pw - 9) / sw + 1;
+  MAAVSS_CHECK_ARG(g->Ho > 0 && g->Wo > 0, "%s: empty output", who);
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv2d_fwd(const float* x, const float* w, float* y, int B, int Ci, int H, int W, int Co, int sh,
+                                 int sw, int pw, int in_layout, void* stream) {
+  MAAVSS_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  C2Geom g;
+  if (int rc = make_c2geom("conv2d_fwd", &g, B, Ci, H, W, Co, sh, sw, pw, in_layout)) return rc;
+  const int64_t total = (int64_t)B * g.Ho * g.Wo * Co;
+  hipLaunchKernelGGL(conv2d_fwd_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, g);
+  MAAVSS_LAUNCH_CHECK("conv2d_fwd_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci, int H, int W, int Co, int sh,
+                                   int sw, int pw, void* stream) {
+  MAAVSS_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
+  C2Geom g;
+  if (int rc = make_c2geom("conv2d_dgrad", &g, B, Ci, H, W, Co, sh, sw, pw, 1)) return rc;
+  const int64_t total = (int64_t)B * H * W * Ci;
+  hipLaunchKernelGGL(conv2d_dgrad_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, g);
+  MAAVSS_LAUNCH_CHECK("conv2d_dgrad_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv2d_wgrad_nchunk(int B, int Ho, int Wo, int Ci, int Co) {
+  const int64_t npos = (int64_t)B * Ho * Wo;
+  int64_t n = 1024 / ((int64_t)Ci * Co);
+  if (n < 1) n = 1;
+  if (n > (npos + 1023) / 1024) n = (npos + 1023) / 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+// ws: nchunk * Co*Ci*27 floats, nchunk = maavss_conv2d_wgrad_nchunk(...)
+extern "C" int maavss_conv2d_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Ci, int H, int W, int Co,
+                                   int sh, int sw, int pw, int in_layout, int beta, void* stream) {
+  MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  C2Geom g;
+  if (int rc = make_c2geom("conv2d_wgrad", &g, B, Ci, H, W, Co, sh, sw, pw, in_layout)) return rc;
+  const int nchunk = maavss_conv2d_wgrad_nchunk(B, g.Ho, g.Wo, Ci, Co);
+  const int64_t npos = (int64_t)B * g.Ho * g.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(Co * Ci, nchunk), dim3(256), 0, st, x, dy, ws, g, (npos + nchunk - 1) / nchunk);
+  MAAVSS_LAUNCH_CHECK("conv2d_wgrad_kernel");
+  const int n = Co * Ci * 27;
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, n, nchunk, beta);
+  MAAVSS_LAUNCH_CHECK("conv2d_wgrad_reduce_kernel");
+  return MAAVSS_OK;
+}

@@ -1,0 +1,578 @@
+// K7/K8: the five Conv3d(k=(3,5,5), stride 1, pad (1,p,p), bias=False) layers of the visual encoder
+// (reference avse_model_final.py:34,39,44,49,54) -- forward, input gradient and weight gradient.
+//
+// Activations are channels-last [B,T,H,W,C] f32 in HBM (C=1 for the network input, so the reference's
+// NCDHW input is used as is).  Three kernel families:
+//   conv3d_c1_*      C_in = 1 (K = 75): direct VALU convolution from an LDS halo tile, weights as
+//                    wave-uniform scalar operands.
+//   conv3d_igemm     C_in in {16,32,64}: implicit GEMM on MFMA.  One workgroup = a 16x16 tile of output
+//                    positions of one (b,t) plane x all C_out.  For each kd the 20x20xC_in input halo is
+//                    staged ONCE into LDS (XOR-swizzled 16-byte chunks) and re-read for the 25 (kh,kw)
+//                    taps; weights stream through a double-buffered LDS tile of 64 k per step.  The same
+//                    kernel computes the input gradient (flipped/transposed weights, pad 4-p).
+//   conv3d_wgrad     dW = sum over positions of x^T . dy; position is the MFMA K dimension, read from
+//                    channels-last LDS tiles with ds_read_b64_tr_b16 (hardware transpose).  A workgroup
+//                    owns one (kd,kh) and the 5 kw taps, walks a chunk of position tiles and writes a
+//                    partial; a second kernel sums the chunks (deterministic, no atomics).
+#include "mma.h"
+
+// --------------------------------------------------------------------------------------------
+// 16-byte-chunk XOR swizzle for an LDS image with rows of RB bytes (RB = 32..256, power of two),
+// so that 16 consecutive rows read at the same chunk hit 16 different 16-byte bank slots.
+template <int RB>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  constexpr int PPR = RB >= 256 ? 1 : 256 / RB;
+  constexpr int NCH = RB / 16;
+  return chunk ^ ((row / PPR) & (NCH - 1));
+}
+
+// --------------------------------------------------------------------------------------------
+// weight re-layout: reference [CO][CI][3][5][5] f32  ->  wt[kd][n][KP] (k = (kh*5+kw)*CIN + ci), elem type.
+//   mode 0 (forward): n = co, CIN = CI, value W[co][ci][kd][kh][kw]
+//   mode 1 (dgrad)  : n = ci, CIN = CO, value W[co][ci][2-kd][4-kh][4-kw]
+template <typename E>
+__global__ void conv3d_prep_w_kernel(const float* __restrict__ w, E* __restrict__ wt, int CO, int CI, int KP, int mode) {
+  const int nN = mode ? CI : CO, cin = mode ? CO : CI;
+  const int64_t total = 3LL * nN * KP;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % KP);
+    const int n = (int)((i / KP) % nN);
+    const int kd = (int)(i / ((int64_t)KP * nN));
+    float v = 0.f;
+    if (kk < 25 * cin) {
+      const int tap = kk / cin, c = kk % cin, kh = tap / 5, kw = tap % 5;
+      if (!mode) v = w[(((int64_t)n * CI + c) * 3 + kd) * 25 + kh * 5 + kw];
+      else v = w[(((int64_t)c * CI + n) * 3 + (2 - kd)) * 25 + (4 - kh) * 5 + (4 - kw)];
+    }
+    if constexpr (sizeof(E) == 2) wt[i] = f2bf(v);
+    else wt[i] = v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+template <bool PRECISE, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restrict__ x,
+                                                           const typename Mma<PRECISE>::elem* __restrict__ wt,
+                                                           float* __restrict__ y, float* __restrict__ stat_partials,
+                                                           int T, int H, int W, int Ho, int Wo, int pad, int KP) {
+  using M = Mma<PRECISE>;
+  using E = typename M::elem;
+  constexpr int ES = sizeof(E), EPC = 16 / ES;       // elements per 16-byte chunk
+  constexpr int RBH = CIN * ES, NCH = RBH / 16;       // halo: bytes / chunks per position
+  constexpr int RBW = 64 * ES, NCW = RBW / 16;        // weight tile: bytes / chunks per row (64 k)
+  constexpr int NT = COUT / 16;
+  constexpr int NCHUNK = (25 * CIN + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  E* halo = reinterpret_cast<E*>(smem);                         // [20*20][CIN] swizzled
+  E* wl = halo + 400 * CIN;                                     // [2][COUT][64] swizzled
+  float* red = reinterpret_cast<float*>(wl + 2 * COUT * 64);    // [4][2][COUT] stats scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+  const int bt = blockIdx.z, t = bt % T;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kd = 0; kd < 3; ++kd) {
+    const int tt = t + kd - 1;
+    if (tt < 0 || tt >= T) continue;  // block-uniform
+    __syncthreads();
+    // ---- stage the 20x20xCIN halo of frame tt (zero-filled outside the image)
+    const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
+    for (int i = tid; i < 400 * (CIN / 4); i += 256) {
+      const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+      const int r = pos / 20, c = pos % 20;
+      const int iy = y0 + r - pad, ix = x0 + c - pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
+      E* d = halo + (pos * NCH + swz<RBH>(c, c4 / EPC)) * EPC + (c4 % EPC);
+      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    }
+    // ---- weight chunk 0 of this kd
+    const E* wk = wt + (int64_t)kd * COUT * KP;
+    for (int i = tid; i < COUT * NCW; i += 256) {
+      const int n = i / NCW, c = i % NCW;
+      *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) =
+          *reinterpret_cast<const uint4*>(wk + (int64_t)n * KP + c * EPC);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+      constexpr int WV = (COUT * NCW + 255) / 256;
+      uint4 wreg[WV];
+      if (ch + 1 < NCHUNK) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+          const int i = v * 256 + tid;
+          if (i < COUT * NCW) wreg[v] = *reinterpret_cast<const uint4*>(wk + (int64_t)(i / NCW) * KP + (ch + 1) * 64 + (i % NCW) * EPC);
+        }
+      }
+      const E* wb = wl + (ch & 1) * COUT * 64;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kk = ch * 64 + s * 32 + 8 * g;
+        int tap = kk / CIN;
+        const int ci = kk % CIN;
+        tap = tap > 24 ? 24 : tap;  // padded tail: weights are zero there
+        const int kh = tap / 5, kw = tap % 5;
+        typename M::frag fa[4], fb[NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = wv * 4 + i + kh, c = l16 + kw;
+          const E* base = halo + (r * 20 + c) * NCH * EPC;
+          if constexpr (PRECISE) {
+            fa[i].lo = *reinterpret_cast<const f32x4*>(base + swz<RBH>(c, ci / EPC) * EPC);
+            fa[i].hi = *reinterpret_cast<const f32x4*>(base + swz<RBH>(c, ci / EPC + 1) * EPC);
+          } else {
+            fa[i] = M::load(base + swz<RBH>(c, ci / EPC) * EPC);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = j * 16 + l16;
+          const E* base = wb + n * 64;
+          const int c0 = (s * 32 + 8 * g) / EPC;
+          if constexpr (PRECISE) {
+            fb[j].lo = *reinterpret_cast<const f32x4*>(base + swz<RBW>(n, c0) * EPC);
+            fb[j].hi = *reinterpret_cast<const f32x4*>(base + swz<RBW>(n, c0 + 1) * EPC);
+          } else {
+            fb[j] = M::load(base + swz<RBW>(n, c0) * EPC);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[i], fb[j]);
+      }
+      if (ch + 1 < NCHUNK) {
+        E* wn = wl + ((ch + 1) & 1) * COUT * 64;
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+          const int i = v * 256 + tid;
+          if (i < COUT * NCW) {
+            const int n = i / NCW, c = i % NCW;
+            *reinterpret_cast<uint4*>(wn + (n * NCW + swz<RBW>(n, c)) * EPC) = wreg[v];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: store + optional per-block BatchNorm partial sums (sum, sum of squares per channel)
+  float* yp = y + (int64_t)bt * Ho * Wo * COUT;
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oy = y0 + wv * 4 + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ox = x0 + g * 4 + r;
+      if (oy < Ho && ox < Wo) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float v = acc[i][j][r];
+          yp[((int64_t)oy * Wo + ox) * COUT + j * 16 + l16] = v;
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      }
+    }
+  }
+  if (stat_partials != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+      if (g == 0) {
+        red[(wv * 2 + 0) * COUT + j * 16 + l16] = s1[j];
+        red[(wv * 2 + 1) * COUT + j * 16 + l16] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const float v = red[tid] + red[2 * COUT + tid] + red[4 * COUT + tid] + red[6 * COUT + tid];
+      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      stat_partials[blk * 2 * COUT + tid] = v;
+    }
+  }
+}
+
+template <bool PRECISE, int CIN, int COUT>
+static int launch_igemm(const float* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
+                        int Wo, int pad, int KP, hipStream_t st) {
+  using E = typename Mma<PRECISE>::elem;
+  const size_t smem = (400 * CIN + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
+  auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT>;
+  if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  dim3 grid(cdiv(Wo, 16), cdiv(Ho, 16), B * T);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, T, H, W, Ho, Wo, pad, KP);
+  return 0;
+}
+
+extern "C" int maavss_conv3d_kp(int c_in) { return ((25 * c_in + 63) / 64) * 64; }
+
+extern "C" int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, int c_in, int mode, int precise, void* stream) {
+  MAAVSS_CHECK_ARG(w && wt, "conv3d_prep_weights: null pointer");
+  const int cin = mode ? c_out : c_in, nN = mode ? c_in : c_out;
+  const int KP = maavss_conv3d_kp(cin);
+  const int64_t total = 3LL * nN * KP;
+  dim3 grid(min(1024, cdiv(total, 256)));
+  if (precise) hipLaunchKernelGGL(conv3d_prep_w_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)wt, c_out, c_in, KP, mode);
+  else hipLaunchKernelGGL(conv3d_prep_w_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wt, c_out, c_in, KP, mode);
+  MAAVSS_LAUNCH_CHECK("conv3d_prep_w_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, float* stat_partials, int B, int T, int H,
+                                   int W, int c_in, int c_out, int pad, int precise, void* stream) {
+  MAAVSS_CHECK_ARG(x && wt && y, "conv3d_igemm: null pointer");
+  MAAVSS_CHECK_ARG(pad >= 0 && pad <= 4, "conv3d_igemm: pad must be in [0,4]");
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
+  MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_igemm: empty output");
+  const int KP = maavss_conv3d_kp(c_in);
+  hipStream_t st = (hipStream_t)stream;
+#define CASE(CI, CO)                                                                                          \
+  if (c_in == CI && c_out == CO) {                                                                            \
+    if (precise) launch_igemm<true, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
+    else launch_igemm<false, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                \
+    MAAVSS_LAUNCH_CHECK("conv3d_igemm_kernel");                                                               \
+    return MAAVSS_OK;                                                                                         \
+  }
+  CASE(16, 32) CASE(32, 64) CASE(64, 64) CASE(64, 16) CASE(32, 16) CASE(64, 32) CASE(16, 64)
+#undef CASE
+  maavss_set_error("conv3d_igemm: unsupported channels %d -> %d", c_in, c_out);
+  return MAAVSS_ERR_ARG;
+}
+
+// --------------------------------------------------------------------------------------------
+// weight gradient
+template <bool PRECISE, int CI, int CO>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ partials, int BT, int T, int H, int W,
+                                                           int Ho, int Wo, int pad, int tiles_x, int tiles_y,
+                                                           int tiles_per_chunk) {
+  using M = Mma<PRECISE>;
+  using E = typename M::elem;
+  constexpr int MT = CI / 16, NT = CO / 16, NPAIR = 5 * MT, PW = (NPAIR + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  E* xs = reinterpret_cast<E*>(smem);  // [16 rows][20 cols][CI]
+  E* ds = xs + 16 * 20 * CI;           // [16][16][CO]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int G = lane >> 4, l16 = lane & 15;
+  const int kd = blockIdx.x / 5, kh = blockIdx.x % 5;
+  f32x4 acc[PW][NT];
+#pragma unroll
+  for (int p = 0; p < PW; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int tile_beg = blockIdx.y * tiles_per_chunk;
+  const int tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y);
+    const int t = bt % T, tt = t + kd - 1;
+    if (tt < 0 || tt >= T) continue;  // block-uniform
+    const int x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CI;
+    for (int i = tid; i < 320 * (CI / 4); i += 256) {
+      const int pos = i / (CI / 4), c4 = (i % (CI / 4)) * 4;
+      const int r = pos / 20, c = pos % 20;
+      const int iy = y0 + r + kh - pad, ix = x0 + c - pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CI + c4);
+      E* d = xs + pos * CI + c4;
+      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    }
+    const float* dp = dy + (int64_t)bt * Ho * Wo * CO;
+    for (int i = tid; i < 256 * (CO / 4); i += 256) {
+      const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
+      const int oy = y0 + pos / 16, ox = x0 + pos % 16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
+      E* d = ds + pos * CO + c4;
+      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {
+      // K step = output rows 2ks, 2ks+1; k = 0..31 -> (row 2ks + k/16, col k%16)
+      typename M::frag fb[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (PRECISE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = 8 * G + e;
+            const float v = ds[((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + l16];
+            if (e < 4) fb[j].lo[e] = v; else fb[j].hi[e - 4] = v;
+          }
+        } else {
+          bf16x4 h[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int k = 8 * G + 4 * hh + (l16 >> 2);
+            const E* a = ds + ((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + (l16 & 3) * 4;
+            h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+          }
+          fb[j] = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        const int q = wv + 4 * p;
+        if (q < NPAIR) {  // wave-uniform
+          const int kw = q / MT, mi = q % MT;
+          typename M::frag fa;
+          if constexpr (PRECISE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int k = 8 * G + e;
+              const float v = xs[((2 * ks + (k >> 4)) * 20 + (k & 15) + kw) * CI + mi * 16 + l16];
+              if (e < 4) fa.lo[e] = v; else fa.hi[e - 4] = v;
+            }
+          } else {
+            bf16x4 h[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int k = 8 * G + 4 * hh + (l16 >> 2);
+              const E* a = xs + ((2 * ks + (k >> 4)) * 20 + (k & 15) + kw) * CI + mi * 16 + (l16 & 3) * 4;
+              h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+            }
+            fa = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) M::mma(acc[p][j], fa, fb[j]);
+        }
+      }
+    }
+  }
+  // partials[chunk][tg][kw][ci][co]
+  float* out = partials + ((int64_t)blockIdx.y * 15 + blockIdx.x) * 5 * CI * CO;
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int q = wv + 4 * p;
+    if (q < NPAIR) {
+      const int kw = q / MT, mi = q % MT;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[((int64_t)kw * CI + mi * 16 + G * 4 + r) * CO + j * 16 + l16] = acc[p][j][r];
+    }
+  }
+}
+
+// dW[co][ci][kd][kh][kw] (+)= sum_chunk partials[chunk][kd*5+kh][kw][ci][co]
+__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int CI,
+                                           int CO, int beta) {
+  const int total = 75 * CI * CO;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % CO, ci = (i / CO) % CI, tap = i / (CO * CI);  // tap = (kd*5+kh)*5+kw
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * total + i];
+    float* d = dw + ((int64_t)co * CI + ci) * 75 + tap;
+    *d = beta ? *d + s : s;
+  }
+}
+
+extern "C" int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk) {
+  return (int64_t)nchunk * 75 * c_in * c_out * 4;
+}
+
+template <bool PRECISE, int CI, int CO>
+static void launch_wgrad(const float* x, const float* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
+                         int nchunk, hipStream_t st) {
+  using E = typename Mma<PRECISE>::elem;
+  const size_t smem = (320 * CI + 256 * CO) * sizeof(E);
+  auto kern = conv3d_wgrad_kernel<PRECISE, CI, CO>;
+  if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int tpc = cdiv(tiles_total, nchunk);
+  hipLaunchKernelGGL(kern, dim3(15, nchunk), dim3(256), smem, st, x, dy, ws, BT, T, H, W, Ho, Wo, pad, tiles_x, tiles_y, tpc);
+}
+
+extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
+                                   int W, int c_in, int c_out, int pad, int beta, int precise, void* stream) {
+  MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_wgrad: null pointer");
+  MAAVSS_CHECK_ARG(nchunk >= 1, "conv3d_wgrad: nchunk must be >= 1");
+  const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
+  MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_wgrad: empty output");
+  hipStream_t st = (hipStream_t)stream;
+#define CASE(CI, CO)                                                                         \
+  if (c_in == CI && c_out == CO) {                                                           \
+    if (precise) launch_wgrad<true, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
+    else launch_wgrad<false, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);    \
+    MAAVSS_LAUNCH_CHECK("conv3d_wgrad_kernel");                                              \
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * CI * CO, 256)), dim3(256), 0, st, ws, dw, nchunk, CI, CO, beta); \
+    MAAVSS_LAUNCH_CHECK("conv3d_wgrad_reduce_kernel");                                       \
+    return MAAVSS_OK;                                                                        \
+  }
+  CASE(16, 32) CASE(32, 64) CASE(64, 64) CASE(64, 16)
+#undef CASE
+  maavss_set_error("conv3d_wgrad: unsupported channels %d -> %d", c_in, c_out);
+  return MAAVSS_ERR_ARG;
+}
+
+// --------------------------------------------------------------------------------------------
+// C_in = 1 (first layer): direct convolution.  x [BT][H][W], w16 [75][16] (tap-major), y [BT][H][W][16].
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w16,
+                                                            float* __restrict__ y, float* __restrict__ stat_partials,
+                                                            int T, int H, int W) {
+  __shared__ float halo[3][20][21];
+  __shared__ float red[4][2][16];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, bt = blockIdx.z, t = bt % T;
+  for (int i = tid; i < 1200; i += 256) {
+    const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
+    const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
+    float v = 0.f;
+    if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(bt + kd - 1) * H + iy) * W + ix];
+    halo[kd][r][c] = v;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const float v = halo[kd][ly + kh][lx + kw];
+        const float* wp = w16 + ((kd * 5 + kh) * 5 + kw) * 16;  // wave-uniform -> scalar loads
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+      }
+  const int oy = y0 + ly, ox = x0 + lx;
+  const bool ok = oy < H && ox < W;
+  if (ok) {
+    float4* o = reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    o[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    o[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+  }
+  if (stat_partials != nullptr) {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float v = ok ? acc[c] : 0.f;
+      const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+      if (lane == 0) { red[wv][0][c] = s1; red[wv][1][c] = s2; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, c = tid & 15;
+      const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      stat_partials[blk * 32 + tid] = v;
+    }
+  }
+}
+
+// reference layout [16][1][3][5][5] -> [75][16]
+__global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __restrict__ w16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 1200) w16[i] = w[(i % 16) * 75 + i / 16];
+}
+
+// dW[16][75] partial per block: thread (tap, position-phase); dy tile and x halo in LDS.
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partials, int T, int H, int W,
+                                                              int tiles_x, int tiles_y, int BT, int tiles_per_chunk) {
+  __shared__ float halo[3][20][21];
+  __shared__ __attribute__((aligned(16))) float dys[256][16];
+  __shared__ float red[3][75][17];
+  const int tid = threadIdx.x;
+  const int tap = tid % 75, ph = tid / 75;  // ph 0..2 active, ph==3 (tid>=225) idle in the MAC loop
+  const int kd = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int tile_beg = blockIdx.x * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y), t = bt % T;
+    const int x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    for (int i = tid; i < 1200; i += 256) {
+      const int d = i / 400, r = (i % 400) / 20, c = i % 20;
+      const int tt = t + d - 1, iy = y0 + r - 2, ix = x0 + c - 2;
+      float v = 0.f;
+      if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(bt + d - 1) * H + iy) * W + ix];
+      halo[d][r][c] = v;
+    }
+    for (int i = tid; i < 1024; i += 256) {
+      const int pos = i >> 2, c4 = (i & 3) * 4;
+      const int oy = y0 + (pos >> 4), ox = x0 + (pos & 15);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < H && ox < W) v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + c4);
+      *reinterpret_cast<float4*>(&dys[pos][c4]) = v;
+    }
+    __syncthreads();
+    if (ph < 3) {
+      for (int pos = ph; pos < 256; pos += 3) {
+        const float xv = halo[kd][(pos >> 4) + kh][(pos & 15) + kw];
+        const float4* d4 = reinterpret_cast<const float4*>(&dys[pos][0]);
+        const float4 a = d4[0], b = d4[1], c = d4[2], d = d4[3];
+        acc[0] = fmaf(xv, a.x, acc[0]); acc[1] = fmaf(xv, a.y, acc[1]); acc[2] = fmaf(xv, a.z, acc[2]); acc[3] = fmaf(xv, a.w, acc[3]);
+        acc[4] = fmaf(xv, b.x, acc[4]); acc[5] = fmaf(xv, b.y, acc[5]); acc[6] = fmaf(xv, b.z, acc[6]); acc[7] = fmaf(xv, b.w, acc[7]);
+        acc[8] = fmaf(xv, c.x, acc[8]); acc[9] = fmaf(xv, c.y, acc[9]); acc[10] = fmaf(xv, c.z, acc[10]); acc[11] = fmaf(xv, c.w, acc[11]);
+        acc[12] = fmaf(xv, d.x, acc[12]); acc[13] = fmaf(xv, d.y, acc[13]); acc[14] = fmaf(xv, d.z, acc[14]); acc[15] = fmaf(xv, d.w, acc[15]);
+      }
+    }
+  }
+  __syncthreads();
+  if (ph < 3)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[ph][tap][c] = acc[c];
+  __syncthreads();
+  for (int i = tid; i < 1200; i += 256) {
+    const int c = i / 75, tp = i % 75;
+    partials[(int64_t)blockIdx.x * 1200 + i] = red[0][tp][c] + red[1][tp][c] + red[2][tp][c];  // [chunk][c][tap]
+  }
+}
+
+__global__ void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1200) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * 1200 + i];
+  dw[i] = beta ? dw[i] + s : s;
+}
+
+extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B,
+                                    int T, int H, int W, void* stream) {
+  MAAVSS_CHECK_ARG(x && w && w16_ws && y, "conv3d_c1_fwd: null pointer");
+  MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "conv3d_c1_fwd: empty problem");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3d_c1_prep_kernel, dim3(5), dim3(256), 0, st, w, w16_ws);
+  hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(cdiv(W, 16), cdiv(H, 16), B * T), dim3(256), 0, st, x, w16_ws, y,
+                     stat_partials, T, H, W);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T,
+                                      int H, int W, int beta, void* stream) {
+  MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_c1_wgrad: null pointer");
+  MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0, "conv3d_c1_wgrad: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
+  const int tiles_total = B * T * tiles_x * tiles_y;
+  hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(nchunk), dim3(256), 0, st, x, dy, ws, T, H, W, tiles_x, tiles_y, B * T,
+                     cdiv(tiles_total, nchunk));
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_kernel");
+  hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(5), dim3(256), 0, st, ws, dw, nchunk, beta);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_reduce_kernel");
+  return MAAVSS_OK;
+}

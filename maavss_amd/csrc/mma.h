@@ -1,0 +1,50 @@
+// MFMA fragment helpers shared by the GEMM-shaped kernels.
+//
+// One inner-loop shape serves both arithmetic modes (include/maavss.h `precise`):
+//   PRECISE=false : LDS holds bf16, one v_mfma_f32_16x16x32_bf16 per 32-deep K step;
+//   PRECISE=true  : LDS holds f32, eight v_mfma_f32_16x16x4_f32 per 32-deep K step.  Lane l keeps the
+//                   same 8 consecutive k (k = 8*(l>>4)+j) as in the bf16 form; MFMA j consumes element j
+//                   of every lane, i.e. the k set {j, 8+j, 16+j, 24+j}; the 8 MFMAs together cover the
+//                   32 k exactly once.  Result is an exact-f32 fma chain (guide: FP32-input MFMA).
+// Operand tiles in LDS are [row][32 k] (k contiguous) for both the M-side and the N-side operand.
+// C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg.
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+template <bool PRECISE>
+struct Mma;
+
+template <>
+struct Mma<false> {
+  using elem = bf16_t;
+  using frag = bf16x8;
+  static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
+  static __device__ __forceinline__ frag load(const elem* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void mma(f32x4& acc, const frag& a, const frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                  __builtin_bit_cast(mfma_bf16x8, b), acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Mma<true> {
+  using elem = float;
+  struct frag {
+    f32x4 lo, hi;
+  };
+  static __device__ __forceinline__ elem cvt(float f) { return f; }
+  static __device__ __forceinline__ frag load(const elem* p) {
+    frag f;
+    f.lo = *reinterpret_cast<const f32x4*>(p);
+    f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+    return f;
+  }
+  static __device__ __forceinline__ void mma(f32x4& acc, const frag& a, const frag& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
+  }
+};

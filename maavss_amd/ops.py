@@ -1,0 +1,271 @@
+"""Thin functional wrappers over the C-ABI (one Python function per entry point family).
+
+Tensors are torch CUDA tensors used purely as device-memory handles: every function passes raw
+device pointers + explicit sizes + the current HIP stream to libmaavss_hip.so.  No torch math here.
+Layouts: visual activations channels-last [B,T,H,W,C]; STFT-encoder activations NHWC.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, query, stream_ptr
+
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2      # gemm / act_bwd
+BN_LEAKY, BN_TANH = 0, 1                        # bn_pool_act
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1                 # torch.nn.BatchNorm defaults used by the reference
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None:
+            _lib.require_cuda(t)
+            assert t.dtype == torch.float32 and t.is_contiguous(), "expected contiguous float32 CUDA tensor"
+
+
+def gemm(a, b, trans_a=False, trans_b=False, act=ACT_NONE, alpha=1.0, out=None, beta=0, precise=False, split_k=0,
+         trans_c=False):
+    """C[M,N] = act(alpha * op(a) @ op(b)^T) (+ C).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b).
+    2-D row-major views with unit inner stride are accepted (row stride = leading dimension)."""
+    for t in (a, b):
+        _lib.require_cuda(t)
+        assert t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    n, k2 = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    assert k == k2, f"gemm: inner dimensions differ ({k} vs {k2})"
+    if out is None:
+        assert beta == 0
+        out = torch.empty((n, m) if trans_c else (m, n), device=a.device, dtype=torch.float32)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.dtype == torch.float32
+    call("maavss_gemm_f32", ptr(a), a.stride(0), int(trans_a), ptr(b), b.stride(0), int(trans_b), ptr(out),
+         out.stride(0), int(trans_c), m, n, k, float(alpha), int(beta), int(act), int(split_k), int(precise),
+         stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- conv3d
+def conv3d_prep(w, mode, precise):
+    """reference-layout weight [Co,Ci,3,5,5] -> re-laid image for conv3d_igemm (mode 0 fwd, 1 dgrad)."""
+    _f32(w)
+    co, ci = w.shape[0], w.shape[1]
+    cin, n = (co, ci) if mode else (ci, co)
+    kp = query("maavss_conv3d_kp", cin)
+    wt = torch.empty(3 * n * kp, device=w.device, dtype=torch.float32 if precise else torch.int16)
+    call("maavss_conv3d_prep_weights", ptr(w), ptr(wt), co, ci, int(mode), int(precise), stream_ptr())
+    return wt
+
+
+def conv3d_igemm(x, wt, c_out, pad, precise, want_stats=False):
+    """x [B,T,H,W,Ci] -> y [B,T,Ho,Wo,c_out] (+ BatchNorm partial sums [nblk,2,c_out])."""
+    _f32(x)
+    b, t, h, w, ci = x.shape
+    ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
+    y = torch.empty(b, t, ho, wo, c_out, device=x.device, dtype=torch.float32)
+    part = None
+    if want_stats:
+        nblk = ((wo + 15) // 16) * ((ho + 15) // 16) * b * t
+        part = torch.empty(nblk, 2, c_out, device=x.device, dtype=torch.float32)
+    call("maavss_conv3d_igemm", ptr(x), ptr(wt), ptr(y), ptr(part), b, t, h, w, ci, c_out, pad, int(precise),
+         stream_ptr())
+    return y, part
+
+
+def wgrad_chunks(b, t, ho, wo):
+    tiles = b * t * ((ho + 15) // 16) * ((wo + 15) // 16)
+    return max(1, min(64, tiles // 4))
+
+
+def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
+    _f32(x, dy, dw)
+    b, t, h, w, ci = x.shape
+    co = dy.shape[-1]
+    ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
+    assert tuple(dy.shape) == (b, t, ho, wo, co)
+    if nchunk is None:
+        nchunk = wgrad_chunks(b, t, ho, wo)
+    ws = torch.empty(query("maavss_conv3d_wgrad_ws_bytes", ci, co, nchunk) // 4, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw = torch.empty(co, ci, 3, 5, 5, device=x.device, dtype=torch.float32)
+        beta = 0
+    call("maavss_conv3d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), nchunk, b, t, h, w, ci, co, pad, int(beta),
+         int(precise), stream_ptr())
+    return dw
+
+
+def conv3d_c1_fwd(x, w, want_stats=False):
+    """x [B,T,H,W] (C=1), w [16,1,3,5,5] -> y [B,T,H,W,16]."""
+    _f32(x, w)
+    b, t, h, wd = x.shape
+    y = torch.empty(b, t, h, wd, 16, device=x.device, dtype=torch.float32)
+    w16 = torch.empty(1200, device=x.device, dtype=torch.float32)
+    part = None
+    if want_stats:
+        part = torch.empty(((wd + 15) // 16) * ((h + 15) // 16) * b * t, 2, 16, device=x.device, dtype=torch.float32)
+    call("maavss_conv3d_c1_fwd", ptr(x), ptr(w), ptr(w16), ptr(y), ptr(part), b, t, h, wd, stream_ptr())
+    return y, part
+
+
+def conv3d_c1_wgrad(x, dy, dw=None, beta=0, nchunk=None):
+    _f32(x, dy, dw)
+    b, t, h, wd = x.shape
+    if nchunk is None:
+        nchunk = max(1, min(1024, (b * t * ((h + 15) // 16) * ((wd + 15) // 16)) // 2))
+    ws = torch.empty(nchunk * 1200, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw = torch.empty(16, 1, 3, 5, 5, device=x.device, dtype=torch.float32)
+        beta = 0
+    call("maavss_conv3d_c1_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), nchunk, b, t, h, wd, int(beta), stream_ptr())
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------- batch norm
+def bn_stats(y2d_rows, c):
+    """y: any contiguous channels-last tensor with last dim c -> partial sums [nblk,2,c]."""
+    _f32(y2d_rows)
+    rows = y2d_rows.numel() // c
+    nblk = query("maavss_bn_stats_nblk", rows)
+    part = torch.empty(nblk, 2, c, device=y2d_rows.device, dtype=torch.float32)
+    call("maavss_bn_stats", ptr(y2d_rows), ptr(part), rows, c, stream_ptr())
+    return part
+
+
+def bn_finalize(part, count, running_mean=None, running_var=None, num_batches_tracked=None, eps=BN_EPS,
+                momentum=BN_MOMENTUM):
+    nblk, _, c = part.shape
+    mean = torch.empty(c, device=part.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    call("maavss_bn_finalize", ptr(part), nblk, c, float(count), float(eps), float(momentum), ptr(mean), ptr(invstd),
+         ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), stream_ptr())
+    return mean, invstd
+
+
+def cl_strides(t, hp, wp, c):
+    """element strides (b, t, pos, c) of a channels-last pooled tensor [B,T,Hp,Wp,C]."""
+    return (t * hp * wp * c, hp * wp * c, c, 1)
+
+
+def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=None):
+    """y [B,T,H,W,C] -> out (default channels-last [B,T,H//p,W//p,C]) and argmax (uint8) when pool > 1."""
+    _f32(y, mean, invstd, gamma, beta)
+    b, t, h, w, c = y.shape
+    hp, wp = h // pool, w // pool
+    if out is None:
+        out = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.float32)
+        strides = cl_strides(t, hp, wp, c)
+    arg = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.uint8) if pool > 1 else None
+    call("maavss_bn_pool_act_fwd", ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(arg), b, t, h,
+         w, c, pool, act, *[int(s) for s in strides], stream_ptr())
+    return out, arg
+
+
+def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,
+                    accumulate=False, dy=None):
+    _f32(y, mean, invstd, gamma)
+    b, t, h, w, c = y.shape
+    hp, wp = h // pool, w // pool
+    if strides is None:
+        strides = cl_strides(t, hp, wp, c)
+    nblk = query("maavss_bn_stats_nblk", b * t * hp * wp)
+    ws = torch.empty(2 * c * nblk + 3 * c, device=y.device, dtype=torch.float32)
+    if dy is None:
+        dy = torch.empty_like(y)
+    call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(dy),
+         ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), b, t, h, w, c, pool, act, *[int(s) for s in strides],
+         stream_ptr())
+    return dy
+
+
+# ---------------------------------------------------------------------------------------------- conv2d
+def conv2d_out(h, w, sh, sw, pw):
+    return (h + 2 - 3) // sh + 1, (w + 2 * pw - 9) // sw + 1
+
+
+def conv2d_fwd(x, w, stride, pw, in_nchw):
+    _f32(x, w)
+    co, ci = w.shape[0], w.shape[1]
+    if in_nchw:
+        b, _, h, wd = x.shape
+    else:
+        b, h, wd, _ = x.shape
+    ho, wo = conv2d_out(h, wd, stride[0], stride[1], pw)
+    y = torch.empty(b, ho, wo, co, device=x.device, dtype=torch.float32)
+    call("maavss_conv2d_fwd", ptr(x), ptr(w), ptr(y), b, ci, h, wd, co, stride[0], stride[1], pw, 0 if in_nchw else 1,
+         stream_ptr())
+    return y
+
+
+def conv2d_dgrad(dy, w, in_hw, stride, pw):
+    _f32(dy, w)
+    co, ci = w.shape[0], w.shape[1]
+    b = dy.shape[0]
+    dx = torch.empty(b, in_hw[0], in_hw[1], ci, device=dy.device, dtype=torch.float32)
+    call("maavss_conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), b, ci, in_hw[0], in_hw[1], co, stride[0], stride[1], pw,
+         stream_ptr())
+    return dx
+
+
+def conv2d_wgrad(x, dy, w_shape, stride, pw, in_nchw, dw=None, beta=0):
+    _f32(x, dy, dw)
+    co, ci = w_shape[0], w_shape[1]
+    if in_nchw:
+        b, _, h, wd = x.shape
+    else:
+        b, h, wd, _ = x.shape
+    ho, wo = dy.shape[1], dy.shape[2]
+    nchunk = query("maavss_conv2d_wgrad_nchunk", b, ho, wo, ci, co)
+    ws = torch.empty(nchunk * co * ci * 27, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw = torch.empty(co, ci, 3, 9, device=x.device, dtype=torch.float32)
+        beta = 0
+    call("maavss_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, ci, h, wd, co, stride[0], stride[1], pw,
+         0 if in_nchw else 1, int(beta), stream_ptr())
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------- lstm
+def lstm_fwd(gx, whh_f, whh_b):
+    """gx [B,L,2,4,256] -> av [B,L,512] and the saved state (hp, gs, cs)."""
+    _f32(gx, whh_f, whh_b)
+    b, l = gx.shape[0], gx.shape[1]
+    dev = gx.device
+    av = torch.empty(b, l, 512, device=dev, dtype=torch.float32)
+    hp = torch.empty(b, l, 2, 256, device=dev, dtype=torch.float32)
+    gs = torch.empty(b, l, 2, 4, 256, device=dev, dtype=torch.float32)
+    cs = torch.empty(b, l, 2, 256, device=dev, dtype=torch.float32)
+    call("maavss_lstm_fwd", ptr(gx), ptr(whh_f), ptr(whh_b), ptr(av), ptr(hp), ptr(gs), ptr(cs), b, l, stream_ptr())
+    return av, hp, gs, cs
+
+
+def lstm_bwd(dav, whh_f, whh_b, gs, cs):
+    _f32(dav, whh_f, whh_b, gs, cs)
+    b, l = dav.shape[0], dav.shape[1]
+    dgx = torch.empty(b, l, 2, 4, 256, device=dav.device, dtype=torch.float32)
+    dc = torch.empty(2, b, 256, device=dav.device, dtype=torch.float32)
+    call("maavss_lstm_bwd", ptr(dav), ptr(whh_f), ptr(whh_b), ptr(gs), ptr(cs), ptr(dgx), ptr(dc), b, l, stream_ptr())
+    return dgx
+
+
+# ---------------------------------------------------------------------------------------------- loss / optimiser
+def act_bwd(dout, out, act):
+    _f32(dout, out)
+    dz = torch.empty_like(out)
+    call("maavss_act_bwd", ptr(dout), ptr(out), ptr(dz), out.numel(), act, stream_ptr())
+    return dz
+
+
+def mse_pair(a_pred, a_tgt, v_pred, v_tgt, coeff, num_seq=1, want_grads=True):
+    """-> losses [3] (a_loss, v_loss, total) and d(total)/d(a_pred), d(total)/d(v_pred)."""
+    _f32(a_pred, a_tgt, v_pred, v_tgt)
+    assert a_pred.shape == a_tgt.shape and v_pred.shape == v_tgt.shape
+    dev = a_pred.device
+    d_a = torch.empty_like(a_pred) if want_grads else None
+    d_v = torch.empty_like(v_pred) if want_grads else None
+    losses = torch.empty(3, device=dev, dtype=torch.float32)
+    ws = torch.empty(1024, device=dev, dtype=torch.float32)
+    call("maavss_mse_pair", ptr(a_pred), ptr(a_tgt), a_pred.numel(), ptr(v_pred), ptr(v_tgt), v_pred.numel(),
+         float(coeff), 1.0 / num_seq, ptr(d_a), ptr(d_v), ptr(losses), ptr(ws), stream_ptr())
+    return losses, d_a, d_v
+
+
+def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    _f32(p, g, m, v)
+    call("maavss_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+         float(eps), int(step), float(grad_scale), stream_ptr())

@@ -1,0 +1,268 @@
+"""GPU unit parity of every HIP kernel family (through the C-ABI) against plain torch fp32 on the CPU.
+
+precise=True  : exact-f32 MFMA / VALU -> fp32 tolerances.
+precise=False : operands rounded to bf16 inside the kernel; the reference is computed in fp32 from the SAME
+                bf16-rounded operands, so only accumulation order differs and the tolerance stays tight.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rt(x):
+    """round to bf16 and back (what precise=False kernels do to MFMA operands)"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, want, rtol, atol, msg=""):
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ----------------------------------------------------------------------------------------------- gemm
+@pytest.mark.parametrize("precise", [True, False])
+@pytest.mark.parametrize("m,n,k,ta,tb", [
+    (2, 4096, 8192, False, False),     # fc1 forward at B=2 (skinny, split-K)
+    (32, 512, 4096, False, False),     # fc2
+    (32, 4112, 512, False, False),     # a_fc1 (N not a multiple of the tile)
+    (512, 2048, 288, False, False),    # LSTM input projection, 224^2 variant (K % 32 != 0)
+    (8192, 4096, 2, True, True),       # dW = dY^T X at B=2 (K=2)
+    (32, 8192, 4096, False, True),     # dX = dY W
+    (1024, 256, 512, True, True),      # dW_hh
+    (130, 70, 100, False, False),      # ragged everything
+])
+def test_gemm(m, n, k, ta, tb, precise):
+    from maavss_amd import ops
+    a = rnd(*((k, m) if ta else (m, k)), seed=1)
+    b = rnd(*((k, n) if tb else (n, k)), seed=2)
+    ar, br = (a, b) if precise else (rt(a), rt(b))
+    want = (ar.t() if ta else ar).double() @ (br if tb else br.t()).double()
+    got = ops.gemm(a.cuda(), b.cuda(), ta, tb, precise=precise)
+    tol = 2e-5 * np.sqrt(k) + 1e-5
+    close(got, want.float(), 1e-4, tol)
+
+
+def test_gemm_epilogues():
+    from maavss_amd import ops
+    a, b = rnd(32, 512, seed=3, scale=0.2), rnd(300, 512, seed=4, scale=0.2)
+    z = a @ b.t()
+    close(ops.gemm(a.cuda(), b.cuda(), act=ops.ACT_TANH, precise=True), torch.tanh(z), 1e-4, 1e-5)
+    close(ops.gemm(a.cuda(), b.cuda(), act=ops.ACT_SIGMOID, precise=True, split_k=4), torch.sigmoid(z), 1e-4, 1e-5)
+    c0 = rnd(32, 300, seed=5)
+    out = c0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), out=out, beta=1, precise=True)
+    close(out, c0 + z, 1e-4, 1e-5)
+    outt = ops.gemm(a.cuda(), b.cuda(), precise=True, trans_c=True)
+    close(outt, z.t().contiguous(), 1e-4, 1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- conv3d
+def to_cl(x):      # NCDHW -> channels-last [B,T,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def from_cl(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("precise", [True, False])
+@pytest.mark.parametrize("ci,co,pad,b,t,h,w", [
+    (16, 32, 2, 1, 3, 20, 36),
+    (32, 64, 2, 2, 2, 16, 16),
+    (64, 64, 2, 1, 4, 28, 28),
+    (64, 16, 3, 2, 3, 10, 10),
+])
+def test_conv3d_igemm_fwd_dgrad_wgrad(ci, co, pad, b, t, h, w, precise):
+    from maavss_amd import ops
+    x = rnd(b, ci, t, h, w, seed=1)
+    wgt = rnd(co, ci, 3, 5, 5, seed=2, scale=(ci * 75) ** -0.5)
+    xr, wr = (x, wgt) if precise else (rt(x), rt(wgt))
+    xr = xr.clone().requires_grad_(True)
+    wr = wr.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, padding=(1, pad, pad))
+    dy = rnd(*y_ref.shape, seed=3)
+    dyr = dy if precise else rt(dy)
+    tol = dict(rtol=2e-4, atol=2e-4)
+
+    x_cl = to_cl(x).cuda()
+    wt = ops.conv3d_prep(wgt.cuda(), 0, precise)
+    y, part = ops.conv3d_igemm(x_cl, wt, co, pad, precise, want_stats=True)
+    close(from_cl(y), y_ref, **tol)
+    # fused BatchNorm partial sums
+    s = part.sum(0).cpu()
+    yr = y_ref.detach()
+    np.testing.assert_allclose(s[0].numpy(), yr.sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(s[1].numpy(), (yr * yr).sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
+
+    # input gradient = the same kernel on flipped / transposed weights with pad 4-p
+    gx_ref, = torch.autograd.grad(y_ref, xr, dyr, retain_graph=True)
+    wtd = ops.conv3d_prep(wgt.cuda(), 1, precise)
+    dx, _ = ops.conv3d_igemm(to_cl(dy).cuda(), wtd, ci, 4 - pad, precise)
+    close(from_cl(dx), gx_ref, **tol)
+
+    gw_ref, = torch.autograd.grad(y_ref, wr, dyr)
+    dw = ops.conv3d_wgrad(x_cl, to_cl(dy).cuda(), pad, precise)
+    scale = gw_ref.abs().max().item()
+    close(dw, gw_ref, 2e-4, 2e-4 * scale + 1e-5)
+    dw2 = ops.conv3d_wgrad(x_cl, to_cl(dy).cuda(), pad, precise, dw=dw.clone(), beta=1, nchunk=3)
+    close(dw2, 2 * gw_ref, 2e-4, 4e-4 * scale + 1e-5)
+
+
+def test_conv3d_c1():
+    from maavss_amd import ops
+    b, t, h, w = 2, 3, 40, 24
+    x = rnd(b, 1, t, h, w, seed=1).requires_grad_(True)
+    wgt = rnd(16, 1, 3, 5, 5, seed=2, scale=0.1).requires_grad_(True)
+    y_ref = F.conv3d(x, wgt, padding=(1, 2, 2))
+    dy = rnd(*y_ref.shape, seed=3)
+    gw_ref, = torch.autograd.grad(y_ref, wgt, dy)
+    xc = x.detach()[:, 0].contiguous().cuda()
+    y, part = ops.conv3d_c1_fwd(xc, wgt.detach().cuda(), want_stats=True)
+    close(from_cl(y), y_ref, 1e-5, 1e-5)
+    s = part.sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), y_ref.detach().sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
+    dw = ops.conv3d_c1_wgrad(xc, to_cl(dy).cuda())
+    close(dw, gw_ref, 1e-4, 1e-4 * gw_ref.abs().max().item())
+
+
+# ----------------------------------------------------------------------------------------------- BN + pool + act
+@pytest.mark.parametrize("c,pool,act,h,w", [(16, 2, 0, 12, 20), (64, 3, 0, 28, 28), (16, 3, 0, 11, 11), (8, 1, 1, 9, 17)])
+def test_bn_pool_act(c, pool, act, h, w):
+    from maavss_amd import ops
+    b, t = 2, 3
+    y = rnd(b, c, t, h, w, seed=1).requires_grad_(True)
+    gamma = (1 + 0.3 * rnd(c, seed=2)).requires_grad_(True)
+    beta = (0.2 * rnd(c, seed=3)).requires_grad_(True)
+    rm, rv = 0.1 * rnd(c, seed=4), 1 + 0.1 * rnd(c, seed=5).abs()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if pool > 1:
+        z = F.max_pool3d(z, (1, pool, pool))
+    out_ref = torch.tanh(z) if act == 1 else F.leaky_relu(z, 0.01)
+    dout = rnd(*out_ref.shape, seed=6)
+    gy, gg, gb = torch.autograd.grad(out_ref, (y, gamma, beta), dout)
+
+    y_cl = to_cl(y.detach()).cuda()
+    part = ops.bn_stats(y_cl, c)
+    rmc, rvc = rm.cuda(), rv.cuda()
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    mean, invstd = ops.bn_finalize(part, b * t * h * w, rmc, rvc, nbt)
+    close(rmc, rm_ref, 1e-5, 1e-6)
+    close(rvc, rv_ref, 1e-5, 1e-6)
+    assert nbt.item() == 1
+    out, arg = ops.bn_pool_act_fwd(y_cl, mean, invstd, gamma.detach().cuda(), beta.detach().cuda(), pool, act)
+    close(from_cl(out), out_ref, 1e-5, 1e-5)
+    dgamma = torch.zeros(c, device="cuda")
+    dbeta = torch.zeros(c, device="cuda")
+    dy = ops.bn_pool_act_bwd(to_cl(dout).cuda(), out, arg, y_cl, mean, invstd, gamma.detach().cuda(), pool, act,
+                             dgamma=dgamma, dbeta=dbeta)
+    close(from_cl(dy), gy, 1e-4, 2e-5)
+    close(dgamma, gg, 1e-4, 1e-4)
+    close(dbeta, gb, 1e-4, 1e-4)
+
+
+def test_bn_pool_strided_output():
+    """last visual stage writes the [B,16,T,S] block of the LSTM sequence buffer directly"""
+    from maavss_amd import ops
+    b, t, c, h, w = 2, 4, 16, 6, 6
+    y = rnd(b, t, h, w, c, seed=1)
+    part = ops.bn_stats(y.cuda(), c)
+    mean, invstd = ops.bn_finalize(part, b * t * h * w)
+    ones, zeros = torch.ones(c).cuda(), torch.zeros(c).cuda()
+    ref, _ = ops.bn_pool_act_fwd(y.cuda(), mean, invstd, ones, zeros, 3, 0)
+    s = 4
+    seq = torch.zeros(b, c, 2 * t * s, device="cuda")
+    ops.bn_pool_act_fwd(y.cuda(), mean, invstd, ones, zeros, 3, 0, out=seq, strides=(c * 2 * t * s, s, 1, 2 * t * s))
+    want = ref.permute(0, 4, 1, 2, 3).reshape(b, c, t * s)
+    assert torch.equal(seq[:, :, :t * s], want) and seq[:, :, t * s:].abs().max().item() == 0
+
+
+# ----------------------------------------------------------------------------------------------- conv2d
+@pytest.mark.parametrize("ci,co,stride,pw,h,w,nchw", [(2, 4, (2, 2), 3, 16, 33, True), (4, 8, (2, 2), 4, 8, 16, False),
+                                                       (16, 16, (1, 2), 4, 8, 32, False), (2, 4, (2, 2), 3, 64, 257, True)])
+def test_conv2d(ci, co, stride, pw, h, w, nchw):
+    from maavss_amd import ops
+    b = 2
+    x = rnd(b, ci, h, w, seed=1).requires_grad_(True)
+    wgt = rnd(co, ci, 3, 9, seed=2, scale=0.2).requires_grad_(True)
+    y_ref = F.conv2d(x, wgt, stride=stride, padding=(1, pw))
+    dy = rnd(*y_ref.shape, seed=3)
+    gx, gw = torch.autograd.grad(y_ref, (x, wgt), dy)
+    xin = x.detach().cuda() if nchw else x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    y = ops.conv2d_fwd(xin, wgt.detach().cuda(), stride, pw, nchw)
+    close(y.permute(0, 3, 1, 2), y_ref, 1e-5, 1e-5)
+    dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = ops.conv2d_dgrad(dyc, wgt.detach().cuda(), (h, w), stride, pw)
+    close(dx.permute(0, 3, 1, 2), gx, 1e-5, 1e-5)
+    dw = ops.conv2d_wgrad(xin, dyc, wgt.shape, stride, pw, nchw)
+    close(dw, gw, 1e-4, 1e-4 * gw.abs().max().item())
+
+
+# ----------------------------------------------------------------------------------------------- LSTM
+@pytest.mark.parametrize("b", [2, 37])
+def test_lstm(b):
+    from maavss_amd import ops
+    l, n_in = 16, 64
+    lstm = torch.nn.LSTM(n_in, 256, 1, bias=False, batch_first=True, bidirectional=True)
+    x = rnd(b, l, n_in, seed=1).requires_grad_(True)
+    out_ref, _ = lstm(x)
+    dout = rnd(*out_ref.shape, seed=2)
+    grads = torch.autograd.grad(out_ref, [x] + list(lstm.parameters()), dout)
+    p = {k: v.detach() for k, v in lstm.named_parameters()}
+    wih = torch.cat([p["weight_ih_l0"], p["weight_ih_l0_reverse"]], 0).cuda()
+    whf, whb = p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda()
+    xc = x.detach().cuda().reshape(b * l, n_in)
+    gx = ops.gemm(xc, wih, precise=True).reshape(b, l, 2, 4, 256)
+    av, hp, gs, cs = ops.lstm_fwd(gx, whf, whb)
+    close(av, out_ref, 1e-4, 1e-5)
+    dgx = ops.lstm_bwd(dout.cuda(), whf, whb, gs, cs).reshape(b * l, 2048)
+    dx = ops.gemm(dgx, wih, trans_b=True, precise=True).reshape(b, l, n_in)
+    close(dx, grads[0], 1e-3, 2e-5)
+    dwih = ops.gemm(dgx, xc, trans_a=True, trans_b=True, precise=True)
+    close(dwih[:1024], grads[1], 1e-3, 1e-4)
+    close(dwih[1024:], grads[3], 1e-3, 1e-4)
+    hp2 = hp.reshape(b * l, 512)
+    dwhf = ops.gemm(dgx[:, :1024], hp2[:, :256], trans_a=True, trans_b=True, precise=True)
+    dwhb = ops.gemm(dgx[:, 1024:], hp2[:, 256:], trans_a=True, trans_b=True, precise=True)
+    close(dwhf, grads[2], 1e-3, 1e-4)
+    close(dwhb, grads[4], 1e-3, 1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- loss / Adam
+def test_mse_pair_and_act_bwd():
+    from maavss_amd import ops
+    a, ta = rnd(4, 2, 8, 257, seed=1).requires_grad_(True), rnd(4, 2, 8, 257, seed=2)
+    v, tv = torch.rand(4, 1, 64, 64, generator=torch.Generator().manual_seed(3)).requires_grad_(True), rnd(4, 1, 64, 64, seed=4)
+    la, lv = F.mse_loss(a, ta), F.mse_loss(v, tv)
+    tot = (la + 0.001 * lv) / 4
+    ga, gv = torch.autograd.grad(tot, (a, v))
+    losses, d_a, d_v = ops.mse_pair(a.detach().cuda(), ta.cuda(), v.detach().cuda(), tv.cuda(), 0.001, 4)
+    close(losses, torch.stack([la, lv, tot]), 1e-5, 1e-7)
+    close(d_a, ga, 1e-5, 1e-9)
+    close(d_v, gv, 1e-5, 1e-10)
+    z = rnd(1000, seed=5).requires_grad_(True)
+    for act, fn in ((1, torch.tanh), (2, torch.sigmoid)):
+        o = fn(z)
+        g, = torch.autograd.grad(o, z, torch.ones_like(o) * 0.5)
+        close(ops.act_bwd(torch.full((1000,), 0.5).cuda(), o.detach().cuda(), act), g, 1e-5, 1e-7)
+
+
+def test_adam_matches_torch():
+    from maavss_amd import ops
+    n = 100003
+    p = torch.nn.Parameter(rnd(n, seed=1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    pc, m, v = p.detach().clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step)
+        p.grad = g.clone()
+        opt.step()
+        ops.adam_step(pc, g.cuda(), m, v, 1e-3, step)
+    close(pc, p.detach(), 1e-5, 1e-6)
