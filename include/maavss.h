@@ -126,6 +126,14 @@ int maavss_mse_pair(const float* a_pred, const float* a_tgt, int64_t na, const f
 int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int64_t step, float grad_scale, void* stream);
 
+/* ---- EXTENSION (no reference counterpart): AdaptiveAvgPool2d closing the STFT encoder for frame sizes the
+ * reference constructor cannot build (224^2, 384^2; SURVEY.md finding 2).  x NHWC [B][H][W][C]; out/dout
+ * addressed b*os_b + (oy*Wo+ox)*os_p + c*os_c. */
+int maavss_adaptive_pool_fwd(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, int64_t os_b,
+                             int64_t os_p, int64_t os_c, void* stream);
+int maavss_adaptive_pool_bwd(const float* dout, float* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t os_b,
+                             int64_t os_p, int64_t os_c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,3 +5,5 @@ Everything numerical runs in hand-written HIP kernels behind the C-ABI of includ
 """
 from . import _lib  # noqa: F401
 from .stft import STFT, calc_hop_size  # noqa: F401
+from .avse import AV_Fusion_Model_Frames  # noqa: F401
+from .trainer import FusedAdam, GradSync, TrainStep, shard_batch  # noqa: F401

@@ -1,0 +1,414 @@
+"""Drop-in `AV_Fusion_Model_Frames` (reference avse_model_final.py:14) on the MI355X HIP kernels.
+
+Same constructor signature, same `forward(x_a, x_v) -> (x_a_out, x_v_out, x_av_fused)`, same
+state_dict keys and tensor shapes as the reference, so a trainer only swaps the import
+(INTEGRATION.md).  The torch.nn modules created here are PARAMETER HOLDERS (they give the reference's
+key names, default initialisation and `.to()/.parameters()/.state_dict()` behaviour); their own
+forward() is never called.  All arithmetic -- forward and the hand-written backward -- goes through
+libmaavss_hip.so (maavss_amd.ops); there is no torch fallback and CPU tensors raise.
+
+Differences from the reference constructor, all documented in DESIGN.md:
+  * shapes are derived analytically (no dry-run tensors, no hard-coded "cuda", no prints, no RNG use);
+  * frame sizes for which the reference's `while` loop never terminates raise ValueError, unless
+    `spatial_match="adaptive"` (keyword-only EXTENSION: closes the STFT encoder with an adaptive average
+    pool; needed for the 224^2 / 384^2 configurations of BASELINE.json);
+  * `precise` (keyword-only): False = bf16 MFMA operands with f32 accumulation (default, the bench
+    path), True = exact-f32 MFMA (parity path).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+LSTM_HIDDEN = 256
+FUSED_DIM = 512
+_VIS_CH = (1, 16, 32, 64, 64)
+_VIS_POOL = (2, 2, 2, 3, 3)
+_VIS_PAD = (2, 2, 2, 2, 3)
+
+
+def visual_spatial_side(width):
+    """avse_model_final.py:33-58: /2 /2 /2 /3, the pad-3 conv adds 2, /3."""
+    side = width // 2 // 2 // 2 // 3
+    return (side + 2) // 3
+
+
+def stft_encoder_plan(t_a, n_bins, t_v, s_v, latent, spatial_match):
+    """avse_model_final.py:82-105 -> ([(c_in, c_out, stride, pad_w)], adaptive_pool_target | None)."""
+    have, want = [t_a, n_bins], [t_v, s_v]
+    plan, c_in = [], 2
+    exact = spatial_match == "exact"
+    while True:
+        can = [have[d] > want[d] and (exact or have[d] // 2 >= want[d]) for d in (0, 1)]
+        if exact:
+            if have == want:
+                break
+            if have[0] < want[0] or have[1] < want[1] or len(plan) > 16:
+                raise ValueError(
+                    f"cannot halve the STFT [{t_a}, {n_bins}] down to the visual code [{t_v}, {s_v}]: the reference "
+                    f"constructor (avse_model_final.py:82) never terminates for this frame size; buildable sizes are "
+                    f"96-167, 240-311, 528-599 px, or pass spatial_match='adaptive'")
+        elif not (can[0] or can[1] or c_in < latent):
+            break
+        c_out = min(2 * c_in, latent)
+        stride = tuple(2 if can[d] else 1 for d in (0, 1))
+        have = [have[d] // 2 if can[d] else have[d] for d in (0, 1)]
+        plan.append((c_in, c_out, stride, 3 if not plan else 4))
+        c_in = c_out
+    return plan, (None if have == want else tuple(want))
+
+
+def stft_decoder_plan(t_a, n_bins, t_v, s_v, latent, c_stft):
+    """avse_model_final.py:155-193 -> [(c_in, c_out, kernel, stride, out_pad, followed_by_bn_tanh)]."""
+    tracked, size = [t_v, s_v], [t_v, s_v]
+    kernel, c_in, plan = (3, 9), latent, []
+    while size != [t_a, n_bins]:
+        if len(plan) > 16:
+            raise ValueError("STFT decoder cannot reach the STFT shape")
+        c_out = max(c_in // 2, c_stft)
+        grow = [tracked[0] < t_a, tracked[1] < n_bins]
+        stride = tuple(2 if g else 1 for g in grow)
+        opad = tuple(1 if g else 0 for g in grow)
+        tracked = [tracked[d] * (2 if grow[d] else 1) for d in (0, 1)]
+        size = [(size[d] - 1) * stride[d] - 2 * (1, 4)[d] + kernel[d] + opad[d] for d in (0, 1)]
+        plan.append((c_in, c_out, kernel, stride, opad, size != [t_a, n_bins]))
+        kernel = (3, 10) if size[1] == (n_bins - 1) // 2 else (3, 9)
+        c_in = c_out
+    return plan
+
+
+class _AVSEFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward and backward are the HIP engine below."""
+
+    @staticmethod
+    def forward(ctx, model, x_a, x_v, *params):
+        outs, saved = model._engine_forward(x_a, x_v, train=model.training)
+        ctx.model, ctx.saved = model, saved
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_a, d_v, d_fused):
+        model = ctx.model
+        names = model._param_names
+        need = {n: ctx.needs_input_grad[3 + i] for i, n in enumerate(names)}
+        grads = model._engine_backward(ctx.saved, d_a, d_v, d_fused, need)
+        ctx.saved = None
+        return (None, None, None) + tuple(grads.get(n) for n in names)
+
+
+class AV_Fusion_Model_Frames(nn.Module):
+    def __init__(self, stft_shape, frame_shape, hops_per_frame, latent_channels=16, fc_size=4096, *,
+                 spatial_match="exact", precise=False):
+        super().__init__()
+        self.stft_shape = list(stft_shape)
+        self.frame_shape = list(frame_shape)
+        self.frame_channels = frame_shape[1]
+        self.latent_channels = latent_channels
+        self.output_stft_frames = hops_per_frame
+        self.precise = bool(precise)
+        if self.frame_channels != 1:
+            raise ValueError("the visual encoder takes single-channel attention frames (avse_model_final.py:34)")
+        if latent_channels not in (16,):
+            # the reference only works when latent_channels equals the STFT encoder's last width (16)
+            raise ValueError("latent_channels must be 16: torch.cat at avse_model_final.py:124 fails otherwise "
+                             "in the reference as well (run_config.py's default 64 crashes there)")
+        self.t_v, self.width = frame_shape[2], frame_shape[-1]
+        if frame_shape[-2] != self.width:
+            raise ValueError("square frames expected")
+        self.t_a, self.n_bins = stft_shape[-2], stft_shape[-1]
+        self.side = visual_spatial_side(self.width)
+        if self.side < 1:
+            raise ValueError("frame too small for the visual encoder")
+        self.s_v = self.side * self.side
+
+        chans = _VIS_CH + (latent_channels,)
+        mods = []
+        for i in range(5):
+            mods += [nn.Conv3d(chans[i], chans[i + 1], (3, 5, 5), 1, (1, _VIS_PAD[i], _VIS_PAD[i]), bias=False),
+                     nn.BatchNorm3d(chans[i + 1]), nn.MaxPool3d((1, _VIS_POOL[i], _VIS_POOL[i])), nn.LeakyReLU()]
+        mods.append(nn.Flatten(-2, -1))
+        self.visual_encoder = nn.Sequential(*mods)
+
+        self._enc_plan, self._enc_pool = stft_encoder_plan(self.t_a, self.n_bins, self.t_v, self.s_v,
+                                                           latent_channels, spatial_match)
+        mods = []
+        for (ci, co, st, pw) in self._enc_plan:
+            mods += [nn.Conv2d(ci, co, (3, 9), st, (1, pw), bias=False), nn.BatchNorm2d(co), nn.Tanh()]
+        if self._enc_pool is not None:
+            mods.append(nn.AdaptiveAvgPool2d(self._enc_pool))
+        self.stft_encoder = nn.Sequential(*mods)
+        if self._enc_plan[-1][1] != latent_channels:
+            raise ValueError("STFT encoder does not end with latent_channels channels")
+
+        self.seq_in = 2 * self.t_v * self.s_v
+        self.lstm = nn.LSTM(input_size=self.seq_in, hidden_size=LSTM_HIDDEN, num_layers=1, bias=False,
+                            batch_first=True, bidirectional=True)
+        flat = latent_channels * 2 * LSTM_HIDDEN          # ctor arg fc_size is overwritten (avse_model_final.py:140)
+        self.fc1 = nn.Linear(flat, flat // 2, bias=False)
+        self.fc2 = nn.Linear(flat // 2, FUSED_DIM, bias=False)
+
+        mods = []
+        if self._enc_pool is None:
+            for (ci, co, k, st, op, bn) in stft_decoder_plan(self.t_a, self.n_bins, self.t_v, self.s_v,
+                                                             latent_channels, stft_shape[1]):
+                mods.append(nn.ConvTranspose2d(ci, co, k, st, (1, 4), op, bias=False))
+                if bn:
+                    mods += [nn.BatchNorm2d(co), nn.Tanh()]
+        self.stft_decoder = nn.Sequential(*mods)
+        self.stft_autoencoder = nn.Sequential(*self.stft_encoder, *self.stft_decoder)
+
+        self.a_fc1 = nn.Sequential(nn.Linear(FUSED_DIM, 2 * hops_per_frame * self.n_bins, bias=False))
+        self.v_fc1 = nn.Sequential(nn.Linear(FUSED_DIM, self.frame_channels * self.width * self.width, bias=False))
+
+        # parameters that take part in forward(), in a fixed order (stft_decoder.* get no gradient, like the reference)
+        self._param_names = [n for n, _ in self.named_parameters()
+                             if not n.startswith("stft_decoder.") and not n.startswith("stft_autoencoder.")]
+
+    # ---- reference API: gradient toggles (avse_model_final.py:216-232) --------------------------------
+    def toggle_fusion_grads(self, toggle):
+        for m in (self.lstm, self.fc1, self.fc2, self.a_fc1, self.v_fc1):
+            m.requires_grad_(toggle)
+
+    def toggle_stft_ae_grads(self, toggle):
+        for m in self.stft_autoencoder:
+            m.requires_grad_(toggle)
+
+    def toggle_enc_grads(self, toggle):
+        for m in self.stft_encoder:
+            m.requires_grad_(toggle)
+        for m in self.visual_encoder:
+            m.requires_grad_(toggle)
+
+    def audio_ae_forward(self, x_a):
+        raise NotImplementedError("stft_autoencoder (ConvTranspose2d decoder) is outside the training hot path of "
+                                  "forward(); scheduled as SURVEY.md 8(f) row f2")
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, x_a, x_v):
+        _lib.require_cuda(x_a, x_v)
+        pd = dict(self.named_parameters())
+        params = [pd[n] for n in self._param_names]
+        return _AVSEFunction.apply(self, x_a, x_v, *params)
+
+    def av_fusion_forward(self, x_a_enc, x_v_enc):
+        raise NotImplementedError("call forward(); the fused engine does not expose the intermediate encodings")
+
+    # ---- engine ---------------------------------------------------------------------------------------
+    def _vis(self, i):
+        return self.visual_encoder[4 * i], self.visual_encoder[4 * i + 1]
+
+    def _aud(self, i):
+        return self.stft_encoder[3 * i], self.stft_encoder[3 * i + 1]
+
+    def _engine_forward(self, x_a, x_v, train=True):
+        if not train:
+            raise NotImplementedError("eval-mode BatchNorm (running statistics) is not part of the training hot path")
+        pr = self.precise
+        b, t, w = x_v.shape[0], self.t_v, self.width
+        assert tuple(x_v.shape[1:]) == (1, t, w, w) and tuple(x_a.shape[1:]) == (2, self.t_a, self.n_bins)
+        x_v = x_v.contiguous().float()
+        x_a = x_a.contiguous().float()
+        dev = x_v.device
+        ts = t * self.s_v
+        seq = torch.empty(b, self.latent_channels, 2 * ts, device=dev, dtype=torch.float32)
+        sv = {"x_v": x_v, "x_a": x_a, "seq": seq, "vis": [], "aud": []}
+        # --- visual encoder (K7-K9)
+        act_in = x_v.view(b, t, w, w)
+        for i in range(5):
+            conv, bn = self._vis(i)
+            co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
+            if i == 0:
+                y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=True)
+            else:
+                wt = ops.conv3d_prep(conv.weight.detach(), 0, pr)
+                y, part = ops.conv3d_igemm(act_in, wt, co, pad, pr, want_stats=True)
+            hh, ww = y.shape[2], y.shape[3]
+            mean, invstd = ops.bn_finalize(part, b * t * hh * ww, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked, bn.eps, bn.momentum)
+            if i < 4:
+                out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
+                strides = None
+            else:   # write the [B,16,T,S] block of the LSTM sequence directly (avse_model_final.py:58,239-240)
+                strides = (self.latent_channels * 2 * ts, self.s_v, 1, 2 * ts)
+                out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY,
+                                               out=seq, strides=strides)
+            sv["vis"].append(dict(x=act_in, y=y, mean=mean, invstd=invstd, out=out, arg=arg, strides=strides))
+            act_in = out
+        # --- STFT encoder (K10)
+        cur, nchw = x_a, True
+        n_layers = len(self._enc_plan)
+        seq_aud = seq.view(-1)[ts:]
+        aud_strides = (self.latent_channels * 2 * ts, 0, 1, 2 * ts)
+        for i, (ci, co, st, pw) in enumerate(self._enc_plan):
+            conv, bn = self._aud(i)
+            y = ops.conv2d_fwd(cur, conv.weight.detach(), st, pw, nchw)
+            ho, wo = y.shape[1], y.shape[2]
+            part = ops.bn_stats(y, co)
+            mean, invstd = ops.bn_finalize(part, b * ho * wo, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                           bn.eps, bn.momentum)
+            y5 = y.view(b, 1, ho, wo, co)
+            last = i == n_layers - 1
+            if last and self._enc_pool is None:
+                out, _ = ops.bn_pool_act_fwd(y5, mean, invstd, bn.weight.detach(), bn.bias.detach(), 1, ops.BN_TANH,
+                                             out=seq_aud, strides=aud_strides)
+                strides = aud_strides
+            else:
+                out, _ = ops.bn_pool_act_fwd(y5, mean, invstd, bn.weight.detach(), bn.bias.detach(), 1, ops.BN_TANH)
+                strides = None
+            sv["aud"].append(dict(x=cur, nchw=nchw, y=y5, mean=mean, invstd=invstd, out=out, strides=strides, hw=(ho, wo)))
+            cur, nchw = out.view(b, ho, wo, co) if strides is None else None, False
+        if self._enc_pool is not None:
+            ho, wo = sv["aud"][-1]["hw"]
+            _lib.call("maavss_adaptive_pool_fwd", cur.data_ptr(), seq_aud.data_ptr(), b, ho, wo, self.latent_channels,
+                      self._enc_pool[0], self._enc_pool[1], self.latent_channels * 2 * ts, 1, 2 * ts, _lib.stream_ptr())
+        # --- fusion: BiLSTM over the 16 channel steps, fc1, fc2 (K11-K13)
+        l = self.latent_channels
+        seq2d = seq.view(b * l, 2 * ts)
+        gx = torch.empty(b * l, 2048, device=dev, dtype=torch.float32)
+        ops.gemm(seq2d, self.lstm.weight_ih_l0.detach(), out=gx[:, :1024], precise=pr, split_k=1)
+        ops.gemm(seq2d, self.lstm.weight_ih_l0_reverse.detach(), out=gx[:, 1024:], precise=pr, split_k=1)
+        av, hp, gs, cs = ops.lstm_fwd(gx.view(b, l, 2, 4, 256), self.lstm.weight_hh_l0.detach(),
+                                      self.lstm.weight_hh_l0_reverse.detach())
+        h1 = ops.gemm(av.view(b, l * 512), self.fc1.weight.detach(), act=ops.ACT_TANH, precise=pr)
+        fused = ops.gemm(h1, self.fc2.weight.detach(), act=ops.ACT_TANH, precise=pr)
+        # --- heads (K14)
+        a = ops.gemm(fused, self.a_fc1[0].weight.detach(), act=ops.ACT_TANH, precise=pr)
+        v = ops.gemm(fused, self.v_fc1[0].weight.detach(), act=ops.ACT_SIGMOID, precise=pr)
+        sv.update(av=av, hp=hp, gs=gs, cs=cs, h1=h1, fused=fused, a=a, v=v)
+        a_out = a.view(b, 2, self.output_stft_frames, self.n_bins)
+        v_out = v.view(b, self.frame_channels, w, w)
+        return (a_out, v_out, fused), sv
+
+    def _engine_backward(self, sv, d_a, d_v, d_fused, need, grads=None, accumulate=False, on_fusion_done=None):
+        """Hand-written backward.  `need[name]` says which parameter gradients are wanted; results go into
+        `grads[name]` (pre-allocated when `grads` is given -- e.g. views of a flat gradient buffer --,
+        `accumulate` then adds instead of overwriting).  `on_fusion_done` is called once the gradients of the
+        LSTM / fc / head weights (98 % of the bytes) are complete, so their all-reduce can overlap the rest."""
+        pr = self.precise
+        out_grads = {}
+        pd = dict(self.named_parameters())
+
+        def gbuf(name):
+            if grads is not None:
+                return grads[name], (1 if accumulate else 0)
+            return torch.empty_like(pd[name]), 0
+
+        def wgrad_gemm(name, dz, x):
+            """dW[N,K] = dz[M,N]^T @ x[M,K]"""
+            if not need.get(name, False):
+                return
+            buf, beta = gbuf(name)
+            ops.gemm(dz, x, trans_a=True, trans_b=True, out=buf, beta=beta, precise=pr)
+            out_grads[name] = buf
+
+        b, l, t = sv["x_v"].shape[0], self.latent_channels, self.t_v
+        ts = t * self.s_v
+        a, v, fused, h1, av = sv["a"], sv["v"], sv["fused"], sv["h1"], sv["av"]
+        # heads
+        dfused = None
+        if d_a is not None:
+            dz_a = ops.act_bwd(d_a.contiguous().view(b, -1), a, ops.ACT_TANH)
+            wgrad_gemm("a_fc1.0.weight", dz_a, fused)
+            dfused = ops.gemm(dz_a, self.a_fc1[0].weight.detach(), trans_b=True, precise=pr)
+        if d_v is not None:
+            dz_v = ops.act_bwd(d_v.contiguous().view(b, -1), v, ops.ACT_SIGMOID)
+            wgrad_gemm("v_fc1.0.weight", dz_v, fused)
+            if dfused is None:
+                dfused = ops.gemm(dz_v, self.v_fc1[0].weight.detach(), trans_b=True, precise=pr)
+            else:
+                ops.gemm(dz_v, self.v_fc1[0].weight.detach(), trans_b=True, out=dfused, beta=1, precise=pr)
+        if d_fused is not None:
+            dfused = d_fused.contiguous().clone() if dfused is None else dfused.add_(d_fused)  # tiny [B,512] glue
+        if dfused is None:
+            raise _lib.MaavssError("backward called without any output gradient")
+        # fc2, fc1
+        dz2 = ops.act_bwd(dfused, fused, ops.ACT_TANH)
+        wgrad_gemm("fc2.weight", dz2, h1)
+        dh1 = ops.gemm(dz2, self.fc2.weight.detach(), trans_b=True, precise=pr)
+        dz1 = ops.act_bwd(dh1, h1, ops.ACT_TANH)
+        avf = av.view(b, l * 512)
+        wgrad_gemm("fc1.weight", dz1, avf)
+        dav = ops.gemm(dz1, self.fc1.weight.detach(), trans_b=True, precise=pr)
+        # LSTM
+        dgx = ops.lstm_bwd(dav.view(b, l, 512), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach(),
+                           sv["gs"], sv["cs"]).view(b * l, 2048)
+        seq2d = sv["seq"].view(b * l, 2 * ts)
+        hp2 = sv["hp"].view(b * l, 512)
+        wgrad_gemm("lstm.weight_ih_l0", dgx[:, :1024], seq2d)
+        wgrad_gemm("lstm.weight_ih_l0_reverse", dgx[:, 1024:], seq2d)
+        wgrad_gemm("lstm.weight_hh_l0", dgx[:, :1024], hp2[:, :256])
+        wgrad_gemm("lstm.weight_hh_l0_reverse", dgx[:, 1024:], hp2[:, 256:])
+        if on_fusion_done is not None:
+            on_fusion_done()
+        enc_need = any(need.get(n, False) for n in self._param_names
+                       if n.startswith("visual_encoder.") or n.startswith("stft_encoder."))
+        if not enc_need:
+            return out_grads
+        dseq = ops.gemm(dgx[:, :1024], self.lstm.weight_ih_l0.detach(), trans_b=True, precise=pr)
+        ops.gemm(dgx[:, 1024:], self.lstm.weight_ih_l0_reverse.detach(), trans_b=True, out=dseq, beta=1, precise=pr)
+        dseq = dseq.view(b, l, 2 * ts)
+
+        def bn_grads(prefix, idx):
+            nw, nb = f"{prefix}.{idx}.weight", f"{prefix}.{idx}.bias"
+            if not (need.get(nw, False) or need.get(nb, False)):
+                return None, None, False
+            gw, beta = gbuf(nw)
+            gb, _ = gbuf(nb)
+            out_grads[nw], out_grads[nb] = gw, gb
+            return gw, gb, bool(beta)
+
+        # --- STFT encoder backward
+        dcur = None
+        n_layers = len(self._enc_plan)
+        seq_aud_grad = dseq.view(-1)[ts:]
+        for i in reversed(range(n_layers)):
+            ci, co, st, pw = self._enc_plan[i]
+            conv, bn = self._aud(i)
+            s = sv["aud"][i]
+            ho, wo = s["hw"]
+            if i == n_layers - 1:
+                if self._enc_pool is not None:
+                    dcur = torch.empty(b, ho, wo, co, device=dseq.device, dtype=torch.float32)
+                    _lib.call("maavss_adaptive_pool_bwd", seq_aud_grad.data_ptr(), dcur.data_ptr(), b, ho, wo, co,
+                              self._enc_pool[0], self._enc_pool[1], l * 2 * ts, 1, 2 * ts, _lib.stream_ptr())
+                    dout, out, strides = dcur.view(b, 1, ho, wo, co), s["out"], None
+                else:
+                    dout, out, strides = seq_aud_grad, sv["seq"].view(-1)[ts:], s["strides"]
+            else:
+                dout, out, strides = dcur.view(b, 1, ho, wo, co), s["out"], None
+            gw, gb, acc = bn_grads("stft_encoder", 3 * i + 1)
+            dy = ops.bn_pool_act_bwd(dout, out, None, s["y"], s["mean"], s["invstd"], bn.weight.detach(), 1, ops.BN_TANH,
+                                     strides=strides, dgamma=gw, dbeta=gb, accumulate=acc).view(b, ho, wo, co)
+            wname = f"stft_encoder.{3 * i}.weight"
+            if need.get(wname, False):
+                buf, beta = gbuf(wname)
+                ops.conv2d_wgrad(s["x"], dy, conv.weight.shape, st, pw, s["nchw"], dw=buf, beta=beta)
+                out_grads[wname] = buf
+            if i > 0:
+                hin, win = sv["aud"][i - 1]["hw"]
+                dcur = ops.conv2d_dgrad(dy, conv.weight.detach(), (hin, win), st, pw)
+        # --- visual encoder backward
+        dcur = None
+        for i in reversed(range(5)):
+            conv, bn = self._vis(i)
+            s = sv["vis"][i]
+            pad, pool = _VIS_PAD[i], _VIS_POOL[i]
+            if i == 4:
+                dout, out = dseq, sv["seq"]
+            else:
+                dout, out = dcur, s["out"]
+            gw, gb, acc = bn_grads("visual_encoder", 4 * i + 1)
+            dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
+                                     ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc)
+            wname = f"visual_encoder.{4 * i}.weight"
+            if need.get(wname, False):
+                buf, beta = gbuf(wname)
+                if i == 0:
+                    ops.conv3d_c1_wgrad(s["x"], dy, dw=buf, beta=beta)
+                else:
+                    ops.conv3d_wgrad(s["x"], dy, pad, pr, dw=buf, beta=beta)
+                out_grads[wname] = buf
+            if i > 0:
+                wtd = ops.conv3d_prep(conv.weight.detach(), 1, pr)
+                dcur, _ = ops.conv3d_igemm(dy, wtd, conv.in_channels, 4 - pad, pr)
+        return out_grads

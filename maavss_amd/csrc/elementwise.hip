@@ -73,6 +73,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// EXTENSION (not in the reference): AdaptiveAvgPool2d that ends the STFT encoder when the frame size is
+// not constructible by halving (224^2, 384^2).  x NHWC [B][H][W][C]; out / dout addressed as
+// b*os_b + (oy*Wo+ox)*os_p + c*os_c (so it can write the LSTM sequence buffer directly).
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                                int H, int W, int C, int Ho, int Wo, int64_t osb,
+                                                                int64_t osp, int64_t osc) {
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C), ox = (int)((i / C) % Wo), oy = (int)((i / ((int64_t)C * Wo)) % Ho), b = (int)(i / ((int64_t)C * Wo * Ho));
+    const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho, x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+    float s = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) s += x[(((int64_t)b * H + yy) * W + xx) * C + c];
+    out[b * osb + ((int64_t)oy * Wo + ox) * osp + c * osc] = s / (float)((y1 - y0) * (x1 - x0));
+  }
+}
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B,
+                                                                int H, int W, int C, int Ho, int Wo, int64_t osb,
+                                                                int64_t osp, int64_t osc) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C), ix = (int)((i / C) % W), iy = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
+    float s = 0.f;
+    for (int oy = 0; oy < Ho; ++oy) {
+      const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho;
+      if (iy < y0 || iy >= y1) continue;
+      for (int ox = 0; ox < Wo; ++ox) {
+        const int x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+        if (ix < x0 || ix >= x1) continue;
+        s += dout[b * osb + ((int64_t)oy * Wo + ox) * osp + c * osc] / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+    dx[i] = s;
+  }
+}
+
 static inline int ew_grid(int64_t n) { return (int)(n / 256 + 1 > 4096 ? 4096 : n / 256 + 1); }
 
 extern "C" int maavss_act_bwd(const float* dout, const float* out, float* dz, int64_t n, int act, void* stream) {
@@ -107,5 +143,22 @@ extern "C" int maavss_adam_step(float* p, const float* g, float* m, float* v, in
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, (float)(lr / bc1),
                      beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   MAAVSS_LAUNCH_CHECK("adam_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_adaptive_pool_fwd(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, int64_t os_b,
+                                        int64_t os_p, int64_t os_c, void* stream) {
+  MAAVSS_CHECK_ARG(x && out && B > 0 && H >= Ho && W >= Wo && Ho > 0 && Wo > 0 && C > 0, "adaptive_pool_fwd: bad arguments");
+  hipLaunchKernelGGL(adaptive_pool_fwd_kernel, dim3(ew_grid((int64_t)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     B, H, W, C, Ho, Wo, os_b, os_p, os_c);
+  MAAVSS_LAUNCH_CHECK("adaptive_pool_fwd_kernel");
+  return MAAVSS_OK;
+}
+extern "C" int maavss_adaptive_pool_bwd(const float* dout, float* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t os_b,
+                                        int64_t os_p, int64_t os_c, void* stream) {
+  MAAVSS_CHECK_ARG(dout && dx && B > 0 && H >= Ho && W >= Wo && Ho > 0 && Wo > 0 && C > 0, "adaptive_pool_bwd: bad arguments");
+  hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dout, dx,
+                     B, H, W, C, Ho, Wo, os_b, os_p, os_c);
+  MAAVSS_LAUNCH_CHECK("adaptive_pool_bwd_kernel");
   return MAAVSS_OK;
 }

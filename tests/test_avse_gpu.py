@@ -1,0 +1,150 @@
+"""GPU parity of the drop-in AV_Fusion_Model_Frames (HIP engine, through the C-ABI) against
+(1) the committed golden vectors produced by the reference's own model (oracle/make_golden.py) and
+(2) the CPU oracle run live on the same seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"avse_{name}.npz"), allow_pickle=False)
+    return z, {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+
+
+def _build(m, precise, spatial_match="exact"):
+    import maavss_amd
+    from oracle import avse_ref_cpu as orc
+    n_bins, t_a = m["fft_len"] // 2 + 1, m["hops_per_frame"] * m["frames"]
+    shapes = ([m["batch"], 2, t_a, n_bins], [m["batch"], 1, m["frames"], m["width"], m["width"]], m["hops_per_frame"])
+    model = maavss_amd.AV_Fusion_Model_Frames(*shapes, precise=precise, spatial_match=spatial_match)
+    twin = orc.AVFusionFramesRef(*shapes, spatial_match=spatial_match)
+    assert list(model.state_dict().keys()) == list(twin.state_dict().keys())
+    model.load_state_dict(orc.seeded_state_dict(twin, m["seed"]), strict=True)
+    batch = orc.synthetic_batch(m["batch"], m["frames"], m["width"], t_a, n_bins, m["hops_per_frame"], m["seed"] + 1)
+    return model.to("cuda"), twin, batch
+
+
+@pytest.mark.parametrize("name", ["S", "P", "L"])
+def test_matches_reference_golden_precise(golden_dir, name):
+    """exact-f32 path: outputs, loss, every parameter gradient, BN running stats and one Adam step."""
+    import maavss_amd
+    z, m = _golden(golden_dir, name)
+    model, _, (x_a, x_v, y_a, y_v) = _build(m, precise=True)
+    model.train()
+    opt = maavss_amd.FusedAdam(model, lr=m["lr"])
+    opt.zero_grad()
+    a, v, fused = model(x_a.cuda(), x_v.cuda())
+    a_loss = torch.nn.functional.mse_loss(a, y_a.cuda())
+    v_loss = torch.nn.functional.mse_loss(v, y_v.cuda())
+    loss = a_loss + m["loss_coeff"] * v_loss
+    loss.backward()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), z["x_a_out"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), z["x_av_fused"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(v.detach().flatten()[::997].cpu().numpy(), z["x_v_out_sample"], rtol=0, atol=3e-5)
+    mse = float(((a.detach().cpu().numpy() - z["x_a_out"]) ** 2).mean())
+    assert mse < 1e-9, mse                       # BASELINE target is 1e-5
+    assert abs(loss.item() - z["loss"]) < 2e-6 and abs(a_loss.item() - z["a_loss"]) < 2e-6
+    params = dict(model.named_parameters())
+    for i, k in enumerate(z["param_names"]):
+        k = str(k)
+        g = params[k].grad
+        if z["grad_norm"][i] < 0:
+            assert g is None or float(g.abs().max()) == 0.0, k       # stft_decoder.*: no gradient in the reference
+            continue
+        gn = g.double().norm().item()
+        assert abs(gn - z["grad_norm"][i]) <= 2e-3 * z["grad_norm"][i] + 1e-7, (k, gn, z["grad_norm"][i])
+        flat = g.flatten()
+        idx = (torch.arange(8) * (flat.numel() - 1)) // 7
+        scale = z["grad_norm"][i] / np.sqrt(flat.numel())
+        np.testing.assert_allclose(flat[idx.cuda()].cpu().numpy(), z["grad_sample"][i], rtol=5e-3, atol=5e-2 * scale, err_msg=k)
+    opt.step()
+    for i, k in enumerate(z["param_names"]):
+        p = params[str(k)].detach().double()
+        assert abs(p.sum().item() - z["adam_wsum"][i]) <= 1e-5 * z["adam_wabs"][i] + 1e-6, k
+        assert abs(p.abs().sum().item() - z["adam_wabs"][i]) <= 1e-5 * z["adam_wabs"][i] + 1e-6, k
+    bufs = dict(model.named_buffers())
+    for i, k in enumerate(z["bn_names"]):
+        k = str(k)
+        assert abs(bufs[k + ".running_mean"].double().sum().item() - z["bn_running_mean_sum"][i]) < 1e-4, k
+        assert abs(bufs[k + ".running_var"].double().sum().item() - z["bn_running_var_sum"][i]) < 1e-3, k
+        assert bufs[k + ".num_batches_tracked"].item() == 1
+
+
+@pytest.mark.parametrize("name", ["P"])
+def test_bf16_path_within_mask_mse_target(golden_dir, name):
+    """bf16-operand MFMA path (what bench.py runs): mask-MSE vs the reference <= 1e-5 (BASELINE.json)."""
+    z, m = _golden(golden_dir, name)
+    model, _, (x_a, x_v, y_a, y_v) = _build(m, precise=False)
+    model.train()
+    a, v, fused = model(x_a.cuda(), x_v.cuda())
+    mse = float(((a.detach().cpu().numpy() - z["x_a_out"]) ** 2).mean())
+    assert mse <= 1e-5, mse
+    loss = torch.nn.functional.mse_loss(a, y_a.cuda()) + m["loss_coeff"] * torch.nn.functional.mse_loss(v, y_v.cuda())
+    assert abs(loss.item() - z["loss"]) < 1e-3
+    loss.backward()
+    params = dict(model.named_parameters())
+    for i, k in enumerate(z["param_names"]):
+        if z["grad_norm"][i] > 0:
+            gn = params[str(k)].grad.double().norm().item()
+            assert abs(gn - z["grad_norm"][i]) <= 0.08 * z["grad_norm"][i] + 1e-7, (str(k), gn, z["grad_norm"][i])
+
+
+def test_trainstep_equals_autograd_path_and_oracle():
+    """The autograd-free TrainStep (bench path) == the nn.Module/autograd path == CPU oracle, incl. Adam."""
+    import maavss_amd
+    from oracle import avse_ref_cpu as orc
+    m = dict(batch=2, frames=8, width=128, fft_len=256, hops_per_frame=8, seed=11)
+    model, twin, (x_a, x_v, y_a, y_v) = _build(m, precise=True)
+    orc.load_seeded(twin, m["seed"])
+    twin.train()
+    opt_ref = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    step = maavss_amd.TrainStep(model, lr=1e-3, loss_coeff=0.001, num_seq=1)
+    for it in range(2):
+        opt_ref.zero_grad()
+        loss_ref, a_ref, v_ref, _ = orc.loss_ref(twin, x_a, x_v, y_a, y_v, 0.001, 1)
+        loss_ref.backward()
+        opt_ref.step()
+        losses = step(x_a.cuda(), x_v.cuda(), y_a.cuda(), y_v.cuda())
+        np.testing.assert_allclose(losses.cpu().numpy(), [a_ref.item(), v_ref.item(), loss_ref.item()], rtol=2e-4, atol=1e-6)
+    ref_params = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder."):
+            continue
+        np.testing.assert_allclose(p.detach().cpu().numpy(), ref_params[k].detach().numpy(), rtol=0, atol=2.5e-3 * 1e-3 * 2 + 1e-6, err_msg=k)
+
+
+def test_adaptive_extension_224_matches_oracle():
+    """224^2 is not constructible in the reference; the 'adaptive' extension is checked against the oracle twin."""
+    from oracle import avse_ref_cpu as orc
+    m = dict(batch=2, frames=4, width=224, fft_len=512, hops_per_frame=8, seed=5)
+    model, twin, (x_a, x_v, y_a, y_v) = _build(m, precise=True, spatial_match="adaptive")
+    orc.load_seeded(twin, m["seed"])
+    twin.train()
+    loss_ref, _, _, (a_ref, v_ref, f_ref) = orc.loss_ref(twin, x_a, x_v, y_a, y_v, 0.001, 1)
+    loss_ref.backward()
+    model.train()
+    a, v, fused = model(x_a.cuda(), x_v.cuda())
+    loss = torch.nn.functional.mse_loss(a, y_a.cuda()) + 0.001 * torch.nn.functional.mse_loss(v, y_v.cuda())
+    loss.backward()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), a_ref.detach().numpy(), rtol=0, atol=3e-5)
+    ref_params = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder.") or ref_params[k].grad is None:
+            continue
+        gr = ref_params[k].grad
+        assert (p.grad.cpu() - gr).norm().item() <= 3e-3 * gr.norm().item() + 1e-7, k
+
+
+def test_reference_constructor_guards():
+    import maavss_amd
+    with pytest.raises(ValueError):
+        maavss_amd.AV_Fusion_Model_Frames([1, 2, 128, 257], [1, 1, 16, 224, 224], 8)
+    with pytest.raises(ValueError):
+        maavss_amd.AV_Fusion_Model_Frames([1, 2, 64, 257], [1, 1, 8, 256, 256], 8, latent_channels=64)
+    model = maavss_amd.AV_Fusion_Model_Frames([1, 2, 64, 257], [1, 1, 8, 256, 256], 8)
+    with pytest.raises(maavss_amd._lib.MaavssError):
+        model(torch.zeros(1, 2, 64, 257), torch.zeros(1, 1, 8, 256, 256))      # CPU tensors: no fallback
