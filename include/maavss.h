@@ -13,8 +13,10 @@
  *   - return value 0 = ok, non-zero = error, text via maavss_last_error() (thread-local);
  *   - tensors are dense, row-major in the documented order; f32 unless stated; "bf16" = raw
  *     uint16 bfloat16 bits;
- *   - `precise` selects the arithmetic of MFMA-backed kernels: 0 = operands rounded to bf16,
- *     f32 accumulate (v_mfma_f32_16x16x32_bf16); 1 = exact f32 MFMA (v_mfma_f32_16x16x4_f32).
+ *   - `precise` (a.k.a. mode) selects the arithmetic of MFMA-backed kernels: 0 = operands rounded to bf16,
+ *     f32 accumulate (v_mfma_f32_16x16x32_bf16); 1 = exact f32 MFMA (v_mfma_f32_16x16x4_f32); 2 = operands
+ *     rounded to IEEE half, f32 accumulate (v_mfma_f32_16x16x32_f16; same rate as bf16, used for forward
+ *     operands whose range BatchNorm bounds).
  */
 #ifndef MAAVSS_H
 #define MAAVSS_H

@@ -30,8 +30,9 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // weight re-layout: reference [CO][CI][3][5][5] f32  ->  wt[kd][n][KP] (k = (kh*5+kw)*CIN + ci), elem type.
 //   mode 0 (forward): n = co, CIN = CI, value W[co][ci][kd][kh][kw]
 //   mode 1 (dgrad)  : n = ci, CIN = CO, value W[co][ci][2-kd][4-kh][4-kw]
-template <typename E>
-__global__ void conv3d_prep_w_kernel(const float* __restrict__ w, E* __restrict__ wt, int CO, int CI, int KP, int mode) {
+template <int PRECISE>
+__global__ void conv3d_prep_w_kernel(const float* __restrict__ w, typename Mma<PRECISE>::elem* __restrict__ wt, int CO, int CI,
+                                     int KP, int mode) {
   const int nN = mode ? CI : CO, cin = mode ? CO : CI;
   const int64_t total = 3LL * nN * KP;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -44,13 +45,12 @@ __global__ void conv3d_prep_w_kernel(const float* __restrict__ w, E* __restrict_
       if (!mode) v = w[(((int64_t)n * CI + c) * 3 + kd) * 25 + kh * 5 + kw];
       else v = w[(((int64_t)c * CI + n) * 3 + (2 - kd)) * 25 + (4 - kh) * 5 + (4 - kw)];
     }
-    if constexpr (sizeof(E) == 2) wt[i] = f2bf(v);
-    else wt[i] = v;
+    wt[i] = Mma<PRECISE>::cvt(v);
   }
 }
 
 // --------------------------------------------------------------------------------------------
-template <bool PRECISE, int CIN, int COUT>
+template <int PRECISE, int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restrict__ x,
                                                            const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                            float* __restrict__ y, float* __restrict__ stat_partials,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
         for (int i = 0; i < 4; ++i) {
           const int r = wv * 4 + i + kh, c = l16 + kw;
           const E* base = halo + (r * 20 + c) * NCH * EPC;
-          if constexpr (PRECISE) {
+          if constexpr (PRECISE == MODE_F32) {
             fa[i].lo = *reinterpret_cast<const f32x4*>(base + swz<RBH>(c, ci / EPC) * EPC);
             fa[i].hi = *reinterpret_cast<const f32x4*>(base + swz<RBH>(c, ci / EPC + 1) * EPC);
           } else {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
           const int n = j * 16 + l16;
           const E* base = wb + n * 64;
           const int c0 = (s * 32 + 8 * g) / EPC;
-          if constexpr (PRECISE) {
+          if constexpr (PRECISE == MODE_F32) {
             fb[j].lo = *reinterpret_cast<const f32x4*>(base + swz<RBW>(n, c0) * EPC);
             fb[j].hi = *reinterpret_cast<const f32x4*>(base + swz<RBW>(n, c0 + 1) * EPC);
           } else {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
   }
 }
 
-template <bool PRECISE, int CIN, int COUT>
+template <int PRECISE, int CIN, int COUT>
 static int launch_igemm(const float* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
                         int Wo, int pad, int KP, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
@@ -222,8 +222,10 @@ extern "C" int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, i
   const int KP = maavss_conv3d_kp(cin);
   const int64_t total = 3LL * nN * KP;
   dim3 grid(min(1024, cdiv(total, 256)));
-  if (precise) hipLaunchKernelGGL(conv3d_prep_w_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)wt, c_out, c_in, KP, mode);
-  else hipLaunchKernelGGL(conv3d_prep_w_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wt, c_out, c_in, KP, mode);
+  MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_prep_weights: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
+  if (precise == MODE_F32) hipLaunchKernelGGL(conv3d_prep_w_kernel<MODE_F32>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)wt, c_out, c_in, KP, mode);
+  else if (precise == MODE_F16) hipLaunchKernelGGL(conv3d_prep_w_kernel<MODE_F16>, grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wt, c_out, c_in, KP, mode);
+  else hipLaunchKernelGGL(conv3d_prep_w_kernel<MODE_BF16>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wt, c_out, c_in, KP, mode);
   MAAVSS_LAUNCH_CHECK("conv3d_prep_w_kernel");
   return MAAVSS_OK;
 }
@@ -232,14 +234,16 @@ extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, flo
                                    int W, int c_in, int c_out, int pad, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && wt && y, "conv3d_igemm: null pointer");
   MAAVSS_CHECK_ARG(pad >= 0 && pad <= 4, "conv3d_igemm: pad must be in [0,4]");
+  MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_igemm: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_igemm: empty output");
   const int KP = maavss_conv3d_kp(c_in);
   hipStream_t st = (hipStream_t)stream;
 #define CASE(CI, CO)                                                                                          \
   if (c_in == CI && c_out == CO) {                                                                            \
-    if (precise) launch_igemm<true, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
-    else launch_igemm<false, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                \
+    if (precise == MODE_F32) launch_igemm<MODE_F32, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);      \
+    else if (precise == MODE_F16) launch_igemm<MODE_F16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else launch_igemm<MODE_BF16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_igemm_kernel");                                                               \
     return MAAVSS_OK;                                                                                         \
   }
@@ -251,7 +255,7 @@ extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, flo
 
 // --------------------------------------------------------------------------------------------
 // weight gradient
-template <bool PRECISE, int CI, int CO>
+template <int PRECISE, int CI, int CO>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ partials, int BT, int T, int H, int W,
                                                            int Ho, int Wo, int pad, int tiles_x, int tiles_y,
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
       typename M::frag fb[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if constexpr (PRECISE) {
+        if constexpr (PRECISE == MODE_F32) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int k = 8 * G + e;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
         if (q < NPAIR) {  // wave-uniform
           const int kw = q / MT, mi = q % MT;
           typename M::frag fa;
-          if constexpr (PRECISE) {
+          if constexpr (PRECISE == MODE_F32) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int k = 8 * G + e;
@@ -385,7 +389,7 @@ extern "C" int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk)
   return (int64_t)nchunk * 75 * c_in * c_out * 4;
 }
 
-template <bool PRECISE, int CI, int CO>
+template <int PRECISE, int CI, int CO>
 static void launch_wgrad(const float* x, const float* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                          int nchunk, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
@@ -402,13 +406,15 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
                                    int W, int c_in, int c_out, int pad, int beta, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_wgrad: null pointer");
   MAAVSS_CHECK_ARG(nchunk >= 1, "conv3d_wgrad: nchunk must be >= 1");
+  MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_wgrad: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_wgrad: empty output");
   hipStream_t st = (hipStream_t)stream;
 #define CASE(CI, CO)                                                                         \
   if (c_in == CI && c_out == CO) {                                                           \
-    if (precise) launch_wgrad<true, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
-    else launch_wgrad<false, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);    \
+    if (precise == MODE_F32) launch_wgrad<MODE_F32, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \
+    else if (precise == MODE_F16) launch_wgrad<MODE_F16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
+    else launch_wgrad<MODE_BF16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_kernel");                                              \
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * CI * CO, 256)), dim3(256), 0, st, ws, dw, nchunk, CI, CO, beta); \
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_reduce_kernel");                                       \

@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int64_t l
   }
 }
 
-template <bool PRECISE, int ROWS>
+template <int PRECISE, int ROWS>
 __device__ __forceinline__ void tile_store(typename Mma<PRECISE>::elem* S, int trans, const float4 (&r)[ROWS / 32]) {
   using M = Mma<PRECISE>;
   const int tid = threadIdx.x;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void tile_store(typename Mma<PRECISE>::elem* S, int t
   }
 }
 
-template <bool PRECISE, int BM, int BN, int WGM, int WGN>
+template <int PRECISE, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using M = Mma<PRECISE>;
   constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
@@ -164,7 +164,7 @@ __global__ void gemm_act_kernel(float* C, int64_t ldc, int rows, int cols, int a
   }
 }
 
-template <bool PRECISE>
+template <int PRECISE>
 static void launch_gemm(GemmArgs g, int cfg, hipStream_t st) {
   if (cfg == 0) {
     dim3 grid(cdiv(g.N, 32), cdiv(g.M, 128), g.split_k);
@@ -185,6 +185,7 @@ extern "C" int maavss_gemm_f32(const float* A, int64_t lda, int transA, const fl
   MAAVSS_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   MAAVSS_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "gemm: dimension too large");
   MAAVSS_CHECK_ARG(beta == 0 || beta == 1, "gemm: beta must be 0 or 1");
+  MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "gemm: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   MAAVSS_CHECK_ARG(act >= 0 && act <= 2, "gemm: act must be 0 (none), 1 (tanh) or 2 (sigmoid)");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g;
@@ -223,8 +224,9 @@ extern "C" int maavss_gemm_f32(const float* A, int64_t lda, int transA, const fl
     hipLaunchKernelGGL(gemm_zero_kernel, dim3(min(2048, cdiv((int64_t)rows * cols, 256))), dim3(256), 0, st, C, ldc,
                        rows, cols);
   }
-  if (precise) launch_gemm<true>(g, cfg, st);
-  else launch_gemm<false>(g, cfg, st);
+  if (precise == MODE_F32) launch_gemm<MODE_F32>(g, cfg, st);
+  else if (precise == MODE_F16) launch_gemm<MODE_F16>(g, cfg, st);
+  else launch_gemm<MODE_BF16>(g, cfg, st);
   MAAVSS_LAUNCH_CHECK("gemm_kernel");
   if (split_k > 1 && act != 0) {
     hipLaunchKernelGGL(gemm_act_kernel, dim3(min(2048, cdiv((int64_t)rows * cols, 256))), dim3(256), 0, st, C, ldc,

@@ -1,8 +1,10 @@
 // MFMA fragment helpers shared by the GEMM-shaped kernels.
 //
-// One inner-loop shape serves both arithmetic modes (include/maavss.h `precise`):
-//   PRECISE=false : LDS holds bf16, one v_mfma_f32_16x16x32_bf16 per 32-deep K step;
-//   PRECISE=true  : LDS holds f32, eight v_mfma_f32_16x16x4_f32 per 32-deep K step.  Lane l keeps the
+// One inner-loop shape serves the three arithmetic modes (include/maavss.h `mode`):
+//   MODE 0 (bf16) : LDS holds bf16, one v_mfma_f32_16x16x32_bf16 per 32-deep K step;
+//   MODE 2 (f16)  : LDS holds IEEE half, one v_mfma_f32_16x16x32_f16 per step (same rate as bf16, 3 more
+//                   mantissa bits: used for forward operands, whose range is bounded by BatchNorm);
+//   MODE 1 (f32)  : LDS holds f32, eight v_mfma_f32_16x16x4_f32 per 32-deep K step.  Lane l keeps the
 //                   same 8 consecutive k (k = 8*(l>>4)+j) as in the bf16 form; MFMA j consumes element j
 //                   of every lane, i.e. the k set {j, 8+j, 16+j, 24+j}; the 8 MFMAs together cover the
 //                   32 k exactly once.  Result is an exact-f32 fma chain (guide: FP32-input MFMA).
@@ -13,11 +15,32 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
-template <bool PRECISE>
+#define MODE_BF16 0
+#define MODE_F32 1
+#define MODE_F16 2
+
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8;
+
+template <int MODE>
 struct Mma;
 
 template <>
-struct Mma<false> {
+struct Mma<MODE_F16> {
+  using elem = unsigned short;  // raw IEEE half bits
+  using frag = bf16x8;
+  static __device__ __forceinline__ elem cvt(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, h);
+  }
+  static __device__ __forceinline__ frag load(const elem* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void mma(f32x4& acc, const frag& a, const frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b),
+                                                 acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Mma<MODE_BF16> {
   using elem = bf16_t;
   using frag = bf16x8;
   static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
@@ -29,7 +52,7 @@ struct Mma<false> {
 };
 
 template <>
-struct Mma<true> {
+struct Mma<MODE_F32> {
   using elem = float;
   struct frag {
     f32x4 lo, hi;

@@ -11,6 +11,7 @@ from ._lib import call, ptr, query, stream_ptr
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2      # gemm / act_bwd
 BN_LEAKY, BN_TANH = 0, 1                        # bn_pool_act
+MODE_BF16, MODE_F32, MODE_F16 = 0, 1, 2         # MFMA operand arithmetic (`precise` argument of the C-ABI)
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1                 # torch.nn.BatchNorm defaults used by the reference
 
 
@@ -48,7 +49,7 @@ def conv3d_prep(w, mode, precise):
     co, ci = w.shape[0], w.shape[1]
     cin, n = (co, ci) if mode else (ci, co)
     kp = query("maavss_conv3d_kp", cin)
-    wt = torch.empty(3 * n * kp, device=w.device, dtype=torch.float32 if precise else torch.int16)
+    wt = torch.empty(3 * n * kp, device=w.device, dtype=torch.float32 if int(precise) == MODE_F32 else torch.int16)
     call("maavss_conv3d_prep_weights", ptr(w), ptr(wt), co, ci, int(mode), int(precise), stream_ptr())
     return wt
 

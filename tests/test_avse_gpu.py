@@ -75,8 +75,9 @@ def test_matches_reference_golden_precise(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["P"])
-def test_bf16_path_within_mask_mse_target(golden_dir, name):
-    """bf16-operand MFMA path (what bench.py runs): mask-MSE vs the reference <= 1e-5 (BASELINE.json)."""
+def test_16bit_path_within_mask_mse_target(golden_dir, name):
+    """16-bit-operand MFMA path (what bench.py runs; f16 forward / bf16 backward operands, f32 accumulate):
+    mask-MSE vs the reference <= 1e-5 (BASELINE.json)."""
     z, m = _golden(golden_dir, name)
     model, _, (x_a, x_v, y_a, y_v) = _build(m, precise=False)
     model.train()
@@ -114,7 +115,7 @@ def test_trainstep_equals_autograd_path_and_oracle():
     for k, p in model.named_parameters():
         if k.startswith("stft_autoencoder."):
             continue
-        np.testing.assert_allclose(p.detach().cpu().numpy(), ref_params[k].detach().numpy(), rtol=0, atol=2.5e-3 * 1e-3 * 2 + 1e-6, err_msg=k)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), ref_params[k].detach().numpy(), rtol=0, atol=5e-5, err_msg=k)   # 2 Adam steps of <= lr = 1e-3 each
 
 
 def test_adaptive_extension_224_matches_oracle():

@@ -12,9 +12,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def rt(x):
-    """round to bf16 and back (what precise=False kernels do to MFMA operands)"""
-    return x.to(torch.bfloat16).to(torch.float32)
+def rt(x, mode=False):
+    """round to bf16 (mode 0/False) or IEEE half (mode 2) and back: what the 16-bit MFMA modes do to operands"""
+    return x.to(torch.float16 if mode == 2 else torch.bfloat16).to(torch.float32)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -72,7 +72,7 @@ def from_cl(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.mark.parametrize("precise", [True, False])
+@pytest.mark.parametrize("precise", [1, 0, 2])
 @pytest.mark.parametrize("ci,co,pad,b,t,h,w", [
     (16, 32, 2, 1, 3, 20, 36),
     (32, 64, 2, 2, 2, 16, 16),
@@ -83,12 +83,12 @@ def test_conv3d_igemm_fwd_dgrad_wgrad(ci, co, pad, b, t, h, w, precise):
     from maavss_amd import ops
     x = rnd(b, ci, t, h, w, seed=1)
     wgt = rnd(co, ci, 3, 5, 5, seed=2, scale=(ci * 75) ** -0.5)
-    xr, wr = (x, wgt) if precise else (rt(x), rt(wgt))
+    xr, wr = (x, wgt) if precise == 1 else (rt(x, precise), rt(wgt, precise))
     xr = xr.clone().requires_grad_(True)
     wr = wr.clone().requires_grad_(True)
     y_ref = F.conv3d(xr, wr, padding=(1, pad, pad))
     dy = rnd(*y_ref.shape, seed=3)
-    dyr = dy if precise else rt(dy)
+    dyr = dy if precise == 1 else rt(dy, precise)
     tol = dict(rtol=2e-4, atol=2e-4)
 
     x_cl = to_cl(x).cuda()
