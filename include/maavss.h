@@ -128,6 +128,30 @@ int maavss_mse_pair(const float* a_pred, const float* a_tgt, int64_t na, const f
 int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int64_t step, float grad_scale, void* stream);
 
+/* ---- K1-K6 DINO ViT-S/8 attention-frame extractor ------------------------------------------------
+ * What VideoAttention._inference (video_attention.py:38-103) obtains from dino's
+ * VisionTransformer.get_last_selfattention (external module, call site video_attention.py:52), batched
+ * over frames.  bf16 = raw uint16 bits.  rows = frames * ntok, ntok = (H/8)*(W/8) + 1.
+ * patchify : frames [F][3][H][W] f32 -> a [rows][192] bf16 (CLS rows zero).
+ * gemm     : C = epilogue(A[M][K] bf16 . W[N][K]^T bf16); N % 128 == 0, K % 64 == 0.  epilogue 0: +bias,
+ *            columns < qscale_cols times qscale -> bf16;  1: +bias, exact GELU -> bf16;  2: C(f32) += acc + bias
+ *            (residual, in place);  3: C(f32) = acc + table[row % period][N] (cls/pos-embed/conv-bias table).
+ * layernorm: x [rows][384] f32 -> bf16 (eps as given, 1e-6 for DINO).
+ * attn     : qkv [rows][ld_qkv] bf16 (q | k | v, heads x 64 each, q pre-scaled) -> out [rows][ld_out] bf16.
+ * cls_attn : last block: softmax of the CLS query over all tokens, CLS column dropped -> att [F][heads][ntok-1] f32.
+ * attn_maps: video_attention.py:80-96 + av_dataset.py:328: head sum, x(1/frame max), nearest x8 upsample,
+ *            x(1/clip max over groups of clip_frames frames; 0 = skip) -> out [F][1][H][W] f32 (zero outside the
+ *            patch grid); ws = F * ((H/8)*(W/8) + 1) floats. */
+int maavss_vit_patchify(const float* frames, void* a, int64_t n_frames, int H, int W, void* stream);
+int maavss_vit_gemm(const void* A, int lda, const void* W, const float* bias, const float* table, int period, void* C,
+                    int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale, void* stream);
+int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int dim,
+                         float eps, void* stream);
+int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, void* stream);
+int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, void* stream);
+int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
+                         int clip_frames, void* stream);
+
 /* ---- EXTENSION (no reference counterpart): AdaptiveAvgPool2d closing the STFT encoder for frame sizes the
  * reference constructor cannot build (224^2, 384^2; SURVEY.md finding 2).  x NHWC [B][H][W][C]; out/dout
  * addressed b*os_b + (oy*Wo+ox)*os_p + c*os_c. */

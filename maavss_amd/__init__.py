@@ -7,3 +7,4 @@ from . import _lib  # noqa: F401
 from .stft import STFT, calc_hop_size  # noqa: F401
 from .avse import AV_Fusion_Model_Frames  # noqa: F401
 from .trainer import FusedAdam, GradSync, TrainStep, shard_batch  # noqa: F401
+from .video_attention import VideoAttention  # noqa: F401

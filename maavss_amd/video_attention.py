@@ -1,0 +1,224 @@
+"""Drop-in `VideoAttention` (reference video_attention.py:24) on the MI355X HIP kernels.
+
+Same constructor arguments and `_inference(frames [T,3,H,W]) -> [T,1,H,W]` contract (CPU float32 result, like
+the reference which fills a CPU tensor frame by frame, video_attention.py:39,96); adds the batched entry
+point `attention_frames(frames [F,3,H,W], clip_frames)` that keeps everything on the GPU and also applies the
+per-clip normalisation of av_dataset.py:328.  The ViT-S/8 (dino.vision_transformer.vit_small(patch_size=8,
+num_classes=0), an un-vendored submodule of the reference) is restated from its published architecture:
+`self.model` is a plain state-dict holder with DINO's key names, so a DINO checkpoint
+(`dino_deitsmall8_pretrain.pth`, key "teacher", prefixes "module."/"backbone." stripped -- video_attention.py:
+116-129) loads unchanged.  There is no network in this environment: if the weights file is absent the
+extractor keeps its seeded random initialisation and says so (the reference would try to download).
+
+The dead sort/cumsum/threshold block of the reference (video_attention.py:59-78) never influences the
+returned frames and is not computed.
+"""
+import math
+import os
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+DIM, DEPTH, HEADS, MLP, PATCH = 384, 12, 6, 1536, 8
+LN_EPS = 1e-6
+EPI_BF16_BIAS, EPI_BF16_BIAS_GELU, EPI_F32_BIAS_RESID, EPI_F32_ROWTABLE = 0, 1, 2, 3
+
+
+def vit_small_shapes(img_size=224):
+    n = (img_size // PATCH) ** 2
+    sh = {"cls_token": (1, 1, DIM), "pos_embed": (1, n + 1, DIM),
+          "patch_embed.proj.weight": (DIM, 3, PATCH, PATCH), "patch_embed.proj.bias": (DIM,),
+          "norm.weight": (DIM,), "norm.bias": (DIM,)}
+    for i in range(DEPTH):
+        p = f"blocks.{i}."
+        sh.update({p + "norm1.weight": (DIM,), p + "norm1.bias": (DIM,),
+                   p + "attn.qkv.weight": (3 * DIM, DIM), p + "attn.qkv.bias": (3 * DIM,),
+                   p + "attn.proj.weight": (DIM, DIM), p + "attn.proj.bias": (DIM,),
+                   p + "norm2.weight": (DIM,), p + "norm2.bias": (DIM,),
+                   p + "mlp.fc1.weight": (MLP, DIM), p + "mlp.fc1.bias": (MLP,),
+                   p + "mlp.fc2.weight": (DIM, MLP), p + "mlp.fc2.bias": (DIM,)})
+    return sh
+
+
+class ViTSmall8Weights:
+    """State-dict holder for the frozen ViT (the object the reference exposes as `VideoAttention.model`)."""
+
+    def __init__(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.sd = {}
+        for k, shape in vit_small_shapes().items():
+            if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k == "norm.weight":
+                t = torch.ones(shape)
+            elif k.endswith(".bias"):
+                t = torch.zeros(shape)
+            else:
+                t = torch.randn(shape, generator=g) * 0.02       # DINO's trunc_normal_(std=.02) scale
+            self.sd[k] = t
+        self.loaded_from = None
+
+    def state_dict(self):
+        return dict(self.sd)
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self.sd if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self.sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"ViT state_dict mismatch: missing {missing[:4]}..., unexpected {unexpected[:4]}...")
+        for k in self.sd:
+            if k in state_dict:
+                t = torch.as_tensor(state_dict[k]).detach().float().cpu()
+                if k != "pos_embed" and tuple(t.shape) != tuple(self.sd[k].shape):
+                    raise RuntimeError(f"shape mismatch for {k}: {tuple(t.shape)} vs {tuple(self.sd[k].shape)}")
+                self.sd[k] = t.clone()
+        return missing, unexpected
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+
+def interpolate_pos_embed(pos_embed, h_tok, w_tok):
+    """Host-side, once per resolution: DINO's bicubic resize of the patch position embedding (incl. its +0.1)."""
+    n = pos_embed.shape[1] - 1
+    if n == h_tok * w_tok and h_tok == w_tok:
+        return pos_embed
+    side = int(math.sqrt(n))
+    patch = pos_embed[:, 1:].reshape(1, side, side, DIM).permute(0, 3, 1, 2)
+    patch = torch.nn.functional.interpolate(patch, scale_factor=((h_tok + 0.1) / side, (w_tok + 0.1) / side),
+                                            mode="bicubic")
+    patch = patch.permute(0, 2, 3, 1).reshape(1, -1, DIM)
+    return torch.cat([pos_embed[:, :1], patch], 1)
+
+
+class VideoAttention:
+    def __init__(self, patch_size=8, threshold=0.6, path_to_weights="dino_deitsmall8_pretrain.pth",
+                 architecture="vit_small", resize=None, device="cuda", frames_per_launch=64):
+        if patch_size != PATCH or architecture != "vit_small":
+            raise ValueError("only DINO vit_small / patch 8 is built (the configuration the reference uses, "
+                             "av_dataset.py:50)")
+        self.resize, self.threshold, self.patch_size = resize, threshold, patch_size
+        self.checkpoint_key = "teacher"
+        self.device = torch.device(device)
+        self.frames_per_launch = frames_per_launch
+        self.model = self.__load_model(path_to_weights)
+        self._dev = None          # device-side weight images, built lazily
+        self._tables = {}
+
+    def __load_model(self, pretrained_weights):
+        model = ViTSmall8Weights()
+        if os.path.isfile(pretrained_weights):
+            sd = torch.load(pretrained_weights, map_location="cpu", weights_only=True)
+            if self.checkpoint_key is not None and self.checkpoint_key in sd:
+                sd = sd[self.checkpoint_key]
+            sd = {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}
+            model.load_state_dict(sd, strict=False)
+            model.loaded_from = pretrained_weights
+        else:
+            print(f"[maavss_amd] DINO weights '{pretrained_weights}' not found and there is no network: "
+                  f"VideoAttention keeps its random initialisation (load one with .model.load_state_dict).")
+        return model
+
+    def load_state_dict(self, sd, strict=True):
+        out = self.model.load_state_dict(sd, strict)
+        self._dev, self._tables = None, {}
+        return out
+
+    # ---- device images of the frozen weights -------------------------------------------------------
+    def _device_weights(self):
+        if self._dev is None:
+            sd, dev = self.model.sd, self.device
+            bf = lambda t: t.to(dev).to(torch.bfloat16).contiguous()     # one-off dtype conversion of frozen weights
+            f32 = lambda t: t.to(dev).float().contiguous()
+            d = {"patch_w": bf(sd["patch_embed.proj.weight"].reshape(DIM, 192))}
+            for i in range(DEPTH):
+                p = f"blocks.{i}."
+                d[i] = dict(n1w=f32(sd[p + "norm1.weight"]), n1b=f32(sd[p + "norm1.bias"]),
+                            qkv_w=bf(sd[p + "attn.qkv.weight"]), qkv_b=f32(sd[p + "attn.qkv.bias"]),
+                            proj_w=bf(sd[p + "attn.proj.weight"]), proj_b=f32(sd[p + "attn.proj.bias"]),
+                            n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
+                            fc1_w=bf(sd[p + "mlp.fc1.weight"]), fc1_b=f32(sd[p + "mlp.fc1.bias"]),
+                            fc2_w=bf(sd[p + "mlp.fc2.weight"]), fc2_b=f32(sd[p + "mlp.fc2.bias"]))
+            self._dev = d
+        return self._dev
+
+    def _row_table(self, h_tok, w_tok):
+        """[ntok][384] f32: row 0 = cls_token + pos[0]; row j = conv bias + pos[j] (prepare_tokens of DINO)."""
+        key = (h_tok, w_tok)
+        if key not in self._tables:
+            sd = self.model.sd
+            pos = interpolate_pos_embed(sd["pos_embed"], h_tok, w_tok)[0]
+            table = pos + sd["patch_embed.proj.bias"][None, :]
+            table[0] = pos[0] + sd["cls_token"][0, 0]
+            self._tables[key] = table.float().contiguous().to(self.device)
+        return self._tables[key]
+
+    # ---- the ViT forward up to the last block's CLS attention ---------------------------------------
+    def cls_attention(self, frames):
+        """frames [F,3,H,W] f32 cuda (H, W multiples of 8 are used) -> [F, 6, (H//8)*(W//8)] f32 cuda."""
+        _lib.require_cuda(frames)
+        assert frames.dim() == 4 and frames.shape[1] == 3 and frames.dtype == torch.float32
+        frames = frames.contiguous()
+        f, _, h, w = frames.shape
+        hp, wp = h // PATCH, w // PATCH
+        ntok = hp * wp + 1
+        rows = f * ntok
+        dev, st = frames.device, stream_ptr()
+        wts, table = self._device_weights(), self._row_table(hp, wp)
+        a = torch.empty(rows, 192, device=dev, dtype=torch.bfloat16)
+        x = torch.empty(rows, DIM, device=dev, dtype=torch.float32)
+        xn = torch.empty(rows, DIM, device=dev, dtype=torch.bfloat16)
+        qkv = torch.empty(rows, 3 * DIM, device=dev, dtype=torch.bfloat16)
+        att_o = torch.empty(rows, DIM, device=dev, dtype=torch.bfloat16)
+        hid = torch.empty(rows, MLP, device=dev, dtype=torch.bfloat16)
+        call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, st)
+        call("maavss_vit_gemm", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
+             EPI_F32_ROWTABLE, 0, 1.0, st)
+        for i in range(DEPTH):
+            b = wts[i]
+            call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
+            call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
+                 3 * DIM, DIM, EPI_BF16_BIAS, DIM, 0.125, st)
+            if i == DEPTH - 1:
+                break
+            call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, st)
+            call("maavss_vit_gemm", ptr(att_o), DIM, ptr(b["proj_w"]), ptr(b["proj_b"]), None, 0, ptr(x), DIM, rows, DIM,
+                 DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
+            call("maavss_vit_layernorm", ptr(x), ptr(b["n2w"]), ptr(b["n2b"]), ptr(xn), rows, DIM, LN_EPS, st)
+            call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["fc1_w"]), ptr(b["fc1_b"]), None, 0, ptr(hid), MLP, rows, MLP, DIM,
+                 EPI_BF16_BIAS_GELU, 0, 1.0, st)
+            call("maavss_vit_gemm", ptr(hid), MLP, ptr(b["fc2_w"]), ptr(b["fc2_b"]), None, 0, ptr(x), DIM, rows, DIM, MLP,
+                 EPI_F32_BIAS_RESID, 0, 1.0, st)
+        att = torch.empty(f, HEADS, ntok - 1, device=dev, dtype=torch.float32)
+        call("maavss_vit_cls_attn", ptr(qkv), ptr(att), f, ntok, HEADS, 3 * DIM, st)
+        return att
+
+    def attention_frames(self, frames, clip_frames=0, out=None):
+        """Batched GPU path: frames [F,3,H,W] -> attention frames [F,1,H,W] (each /frame max; with
+        clip_frames = T additionally /clip max over consecutive groups of T frames, av_dataset.py:328).
+        Frames are processed `frames_per_launch` at a time so the inter-kernel tensors stay Infinity-Cache sized."""
+        _lib.require_cuda(frames)
+        f, _, h, w = frames.shape
+        if out is None:
+            out = torch.empty(f, 1, h, w, device=frames.device, dtype=torch.float32)
+        step = self.frames_per_launch
+        if clip_frames:
+            step = max(clip_frames, (step // clip_frames) * clip_frames)
+        hp, wp = h // PATCH, w // PATCH
+        for s in range(0, f, step):
+            e = min(f, s + step)
+            att = self.cls_attention(frames[s:e])
+            ws = torch.empty((e - s) * (hp * wp + 1), device=frames.device, dtype=torch.float32)
+            call("maavss_vit_attn_maps", ptr(att), ptr(out[s:e]), ptr(ws), e - s, HEADS, h, w, int(clip_frames),
+                 stream_ptr())
+        return out
+
+    def _inference(self, frames):
+        """Reference contract (video_attention.py:38-103): [T,3,H,W] float -> [T,1,H,W] float32 on the CPU."""
+        dev_frames = frames.to(self.device, dtype=torch.float32)
+        if self.resize is not None:
+            raise NotImplementedError("resize is unused by the reference's _inference and is not built")
+        return self.attention_frames(dev_frames, clip_frames=0).cpu()

@@ -1,0 +1,128 @@
+"""GPU parity of the ViT-S/8 attention extractor kernels (through the C-ABI) against torch fp32 on the CPU.
+
+The ViT has no reference oracle (dino is an empty submodule of the reference): the end-to-end
+check is against oracle/vit_ref_cpu.py (restated architecture, cross-checked against transformers.ViTModel in
+tests/test_oracle_cpu.py) -- "parity unpinned" to the reference itself.  Kernel-level checks feed the torch
+reference the SAME bf16-rounded operands, so their tolerances only cover accumulation order / bf16 outputs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _call(name, *args):
+    from maavss_amd import _lib
+    _lib.call(name, *args)
+
+
+def _st():
+    from maavss_amd import _lib
+    return _lib.stream_ptr()
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 1152, 384), (785 * 3, 384, 1536), (130, 1536, 384), (197, 384, 192)])
+def test_vit_gemm_epilogues(m, n, k):
+    a, w, bias = bf(rnd(m, k, seed=1)), bf(rnd(n, k, seed=2, scale=k ** -0.5)), rnd(n, seed=3, scale=0.1)
+    z = a.float() @ w.float().t() + bias
+    ac, wc, bc = a.cuda(), w.cuda(), bias.cuda()
+    # 0: +bias, q-scale on the first 384 columns -> bf16
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 0, 384, 0.125, _st())
+    want = z.clone()
+    want[:, :384] *= 0.125
+    np.testing.assert_allclose(c.float().cpu().numpy(), want.numpy(), rtol=1e-2, atol=1e-2)
+    # 1: +bias, GELU -> bf16
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 1, 0, 1.0, _st())
+    np.testing.assert_allclose(c.float().cpu().numpy(), F.gelu(z).numpy(), rtol=1e-2, atol=1e-2)
+    # 2: residual in place, f32
+    res = rnd(m, n, seed=4)
+    x = res.clone().cuda()
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, x.data_ptr(), n, m, n, k, 2, 0, 1.0, _st())
+    np.testing.assert_allclose(x.cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=2e-4)
+    # 3: periodic row table
+    period = 197 if m % 197 == 0 else 13
+    table = rnd(period, n, seed=5)
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), None, table.cuda().data_ptr(), period, x.data_ptr(), n, m, n, k, 3, 0, 1.0, _st())
+    want = (a.float() @ w.float().t()) + table[torch.arange(m) % period]
+    np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_vit_layernorm_and_patchify():
+    rows = 1003
+    x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
+    y = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
+    _call("maavss_vit_layernorm", x.cuda().data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), y.data_ptr(), rows, 384, 1e-6, _st())
+    want = F.layer_norm(x, (384,), g, b, 1e-6)
+    np.testing.assert_allclose(y.float().cpu().numpy(), want.numpy(), rtol=8e-3, atol=8e-3)
+    fr = rnd(3, 3, 40, 24, seed=4)
+    ntok = 5 * 3 + 1
+    a = torch.empty(3 * ntok, 192, dtype=torch.bfloat16, device="cuda")
+    _call("maavss_vit_patchify", fr.cuda().data_ptr(), a.data_ptr(), 3, 40, 24, _st())
+    want = F.unfold(fr, 8, stride=8).transpose(1, 2)          # [3, 15, 192] in (c, dy, dx) order
+    got = a.float().cpu().view(3, ntok, 192)
+    assert got[:, 0].abs().max().item() == 0
+    np.testing.assert_allclose(got[:, 1:].numpy(), bf(want).float().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("ntok,frames", [(785, 2), (65, 3), (1025, 1)])
+def test_vit_attention_and_cls(ntok, frames):
+    rows = frames * ntok
+    qkv = bf(rnd(rows, 1152, seed=1, scale=1.0))
+    qkv[:, :384] *= 0.125 * 3                                  # q already carries the 1/8 scale (sharpened a little)
+    out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
+    _call("maavss_vit_attn", qkv.cuda().data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
+    q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.float().split(384, 1)]
+    p = (q @ k.transpose(-1, -2)).softmax(-1)
+    want = (p @ v).transpose(1, 2).reshape(rows, 384)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), rtol=2e-2, atol=8e-3)
+    att = torch.empty(frames, 6, ntok - 1, device="cuda")
+    _call("maavss_vit_cls_attn", qkv.cuda().data_ptr(), att.data_ptr(), frames, ntok, 6, 1152, _st())
+    np.testing.assert_allclose(att.cpu().numpy(), p[:, :, 0, 1:].numpy(), rtol=1e-3, atol=1e-7)
+
+
+def test_attn_maps_postprocess():
+    from oracle import vit_ref_cpu as vref
+    f, hp, wp = 6, 5, 4
+    att = torch.rand(f, 6, hp * wp, generator=torch.Generator().manual_seed(2))
+    out = torch.empty(f, 1, hp * 8 + 4, wp * 8, device="cuda")
+    ws = torch.empty(f * (hp * wp + 1), device="cuda")
+    _call("maavss_vit_attn_maps", att.cuda().data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8 + 4, wp * 8, 3, _st())
+    want = torch.zeros(f, 1, hp * 8 + 4, wp * 8)
+    for c in range(2):
+        fr = vref.attention_frames_from_cls(att[3 * c:3 * c + 3], hp, wp)
+        want[3 * c:3 * c + 3, :, :hp * 8] = vref.clip_normalise_ref(fr).permute(1, 0, 2, 3)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("width,frames", [(64, 4), (224, 2)])
+def test_video_attention_matches_oracle(width, frames):
+    import maavss_amd
+    from oracle import vit_ref_cpu as vref
+    sd = vref.seeded_vit_state(3)
+    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth")
+    va.load_state_dict(sd)
+    fr = vref.synthetic_frames(frames, width, 5)
+    with torch.no_grad():
+        want_cls = vref.cls_attention(sd, fr)
+        want = vref.inference_ref(sd, fr)
+    got_cls = va.cls_attention(fr.cuda()).cpu()
+    # bf16 activations through 12 blocks: compare the attention distributions, then the normalised maps
+    err = (got_cls - want_cls).abs().max().item() / want_cls.abs().max().item()
+    assert err < 0.05, err
+    cos = F.cosine_similarity(got_cls.flatten(1), want_cls.flatten(1)).min().item()
+    assert cos > 0.999, cos
+    got = va._inference(fr)
+    assert got.shape == want.shape and got.device.type == "cpu"
+    assert (got - want).abs().max().item() < 0.05
+    assert (got - want).abs().mean().item() < 5e-3
