@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- train clips/s of the MAAVSS hot path on MI355X (BASELINE.json metric, config[1]).
+
+One "step" = one batch of synthetic clips through the whole hot path, all of it in libmaavss_hip.so:
+  frames [B*T,3,W,W] --ViT-S/8 attention extraction (fwd only)--> attention frames [B,1,T,W,W]
+  audio  [B,L]       --STFT + noise--> x_stft, y_stft [B,2,T_a,F]
+  AV_Fusion_Model_Frames forward + backward (+ RCCL gradient all-reduce when N>1) + Adam.
+Inputs are generated once and are resident in HBM before the timed region (SURVEY.md 8d recipe).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU, weak scaling (B clips per GPU)
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed
+over the timed region) and `cpu_baseline` (the CPU oracle = validated port of the reference path, timed on the
+host cores in the same run, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--framesize", type=int, default=224)
+    ap.add_argument("--fft_len", type=int, default=512)
+    ap.add_argument("--hops_per_frame", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--precise", action="store_true", help="exact-f32 MFMA in the fusion network (parity mode)")
+    return ap.parse_args()
+
+
+def synthetic_inputs(torch, batch, frames, width, length, seed, device):
+    """U[0,1) RGB, ImageNet-normalised; audio = 0.1*N(0,1) + 3 sinusoids, clipped."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand(batch * frames, 3, width, width, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]
+    x = (x - mean) / std
+    t = torch.arange(length, dtype=torch.float32) / 16000.0
+    a = 0.1 * torch.randn(batch, length, generator=g)
+    for f in (220.0, 440.0, 880.0):
+        ph = torch.rand(batch, 1, generator=g) * 2 * math.pi
+        a = a + 0.2 * torch.sin(2 * math.pi * f * t[None, :] + ph)
+    return x.to(device), a.clamp(-1, 1).to(device)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (validated restatement of the reference path, oracle/) on the host cores: one clip
+    end to end = ViT attention frames for T frames + STFT + one AVSE train step (fwd+bwd+Adam)."""
+    import torch
+    from oracle import avse_ref_cpu as orc, stft_ref_cpu as sref, vit_ref_cpu as vref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t, w, hpf = args.frames, args.framesize, args.hops_per_frame
+    hop, length, t_a = sref.calc_hop_size(t, hpf, 30, 16000)
+    n_bins = args.fft_len // 2 + 1
+    b = 1
+    sd = vref.seeded_vit_state(3)
+    side_ok = orc.visual_side(w)
+    model = orc.AVFusionFramesRef([b, 2, t_a, n_bins], [b, 1, t, w, w], hpf, spatial_match="adaptive")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    model.train()
+    frames = vref.synthetic_frames(b * t, w, 1)
+    audio = sref.synthetic_audio(b, length, 2)
+
+    def one_clip():
+        with torch.no_grad():
+            att = vref.clip_normalise_ref(vref.inference_ref(sd, frames))[None]           # [1,1,T,H,W]
+            y = sref.stft_ref(audio, args.fft_len, hop)
+            x = y + 0.1 * torch.randn_like(y)
+        mid = t // 2
+        opt.zero_grad()
+        loss, *_ = orc.loss_ref(model, x, att, y[:, :, mid * hpf:(mid + 1) * hpf], att[:, :, mid], 0.001, 1)
+        loss.backward()
+        opt.step()
+
+    one_clip()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 8):
+        one_clip()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * b / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n} clips of {t}x{w}x{w} frames + {args.fft_len}-pt STFT, batch 1, fp32 torch CPU oracle "
+                      f"(ViT-S/8 fwd + STFT + AVSE fwd/bwd/Adam), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE (launch with torch.distributed.run)",
+              file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    import maavss_amd
+    from maavss_amd import _lib
+    b, t, w, hpf = args.batch, args.frames, args.framesize, args.hops_per_frame
+    hop, length, t_a = maavss_amd.calc_hop_size(t, hpf, 30, 16000)
+    n_bins = args.fft_len // 2 + 1
+    torch.manual_seed(1234 + rank)
+    frames, audio = synthetic_inputs(torch, b, t, w, length, 1234 + rank, dev)
+
+    va = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth", device=dev)   # random init: no network
+    stft = maavss_amd.STFT(args.fft_len, hop, noise_std=0.1, device=dev)
+    try:
+        model = maavss_amd.AV_Fusion_Model_Frames([b, 2, t_a, n_bins], [b, 1, t, w, w], hpf, precise=args.precise)
+        spatial = "exact"
+    except ValueError:
+        model = maavss_amd.AV_Fusion_Model_Frames([b, 2, t_a, n_bins], [b, 1, t, w, w], hpf, precise=args.precise,
+                                                  spatial_match="adaptive")
+        spatial = "adaptive"
+    model = model.to(dev).train()
+    step_fn = maavss_amd.TrainStep(model, lr=1e-5, loss_coeff=0.001, num_seq=1)
+    mid = t // 2
+    attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
+
+    def step(i):
+        va.attention_frames(frames, clip_frames=t, out=attn)
+        x_v = attn.view(b, 1, t, w, w)
+        x_stft, y_stft = stft(audio, seed=i)
+        y_a = y_stft[:, :, mid * hpf:(mid + 1) * hpf, :]
+        y_v = x_v[:, :, mid]
+        return step_fn(x_stft, x_v, y_a, y_v)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _lib.set_timer(None)
+    if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = el.item()
+    loss_val = float(losses[2].item())
+
+    if rank == 0:
+        summ = timer.summary()
+        # ---- roofline of the dominant kernel family (by accumulated HIP-event time)
+        def flops_of(name, a):
+            if name == "maavss_vit_gemm":
+                return 2.0 * a[8] * a[9] * a[10]                  # M, N, K
+            if name == "maavss_vit_attn":
+                return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
+            return 0.0
+        by_time = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
+        dom_name, dom = by_time[0]
+        roofline = None
+        for name, d in by_time:
+            fl = sum(flops_of(name, a) for a in d["args"])
+            if fl > 0:
+                avg_ms = d["ms"] / d["calls"]
+                achieved = fl / d["calls"] / (avg_ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
+                            "share_of_kernel_time": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3)}
+                break
+        breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:12]}
+        with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+            metric = json.load(fh)["metric"]
+        clips = b * world * args.steps
+        out = {
+            "metric": metric, "value": round(clips / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precise else "bf16", "data": "synthetic",
+            "config": {"workload": f"batch={b}/GPU, {t} frames {w}x{w}, {args.fft_len}-pt STFT, ViT-S/8 attention extraction "
+                                   f"(bf16 MFMA) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
+                       "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
+                       "parallelism": f"dp{world}", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
+                       "loss": loss_val},
+            "roofline": roofline,
+            "kernel_ms_per_step": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

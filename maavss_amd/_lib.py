@@ -77,8 +77,43 @@ def lib():
     return _lib
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (torch's current
+    stream is the stream every entry point launches on).  Used by bench.py for the roofline numbers."""
+
+    def __init__(self):
+        self.records = []          # (name, args, start_event, end_event)
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, args, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": []})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["args"].append(args)
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
 def call(name, *args):
+    if _timer is None:
+        lib().call(name, *args)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     lib().call(name, *args)
+    e1.record()
+    _timer.records.append((name, args, e0, e1))
 
 
 def query(name, *args):

@@ -53,7 +53,8 @@ def test_vit_gemm_epilogues(m, n, k):
     # 3: periodic row table
     period = 197 if m % 197 == 0 else 13
     table = rnd(period, n, seed=5)
-    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), None, table.cuda().data_ptr(), period, x.data_ptr(), n, m, n, k, 3, 0, 1.0, _st())
+    tc = table.cuda()
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), None, tc.data_ptr(), period, x.data_ptr(), n, m, n, k, 3, 0, 1.0, _st())
     want = (a.float() @ w.float().t()) + table[torch.arange(m) % period]
     np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
 
@@ -62,13 +63,15 @@ def test_vit_layernorm_and_patchify():
     rows = 1003
     x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
     y = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
-    _call("maavss_vit_layernorm", x.cuda().data_ptr(), g.cuda().data_ptr(), b.cuda().data_ptr(), y.data_ptr(), rows, 384, 1e-6, _st())
+    xc, gc, bc = x.cuda(), g.cuda(), b.cuda()      # keep the device tensors alive across the call
+    _call("maavss_vit_layernorm", xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), rows, 384, 1e-6, _st())
     want = F.layer_norm(x, (384,), g, b, 1e-6)
     np.testing.assert_allclose(y.float().cpu().numpy(), want.numpy(), rtol=8e-3, atol=8e-3)
     fr = rnd(3, 3, 40, 24, seed=4)
     ntok = 5 * 3 + 1
     a = torch.empty(3 * ntok, 192, dtype=torch.bfloat16, device="cuda")
-    _call("maavss_vit_patchify", fr.cuda().data_ptr(), a.data_ptr(), 3, 40, 24, _st())
+    frc = fr.cuda()
+    _call("maavss_vit_patchify", frc.data_ptr(), a.data_ptr(), 3, 40, 24, _st())
     want = F.unfold(fr, 8, stride=8).transpose(1, 2)          # [3, 15, 192] in (c, dy, dx) order
     got = a.float().cpu().view(3, ntok, 192)
     assert got[:, 0].abs().max().item() == 0
@@ -81,13 +84,14 @@ def test_vit_attention_and_cls(ntok, frames):
     qkv = bf(rnd(rows, 1152, seed=1, scale=1.0))
     qkv[:, :384] *= 0.125 * 3                                  # q already carries the 1/8 scale (sharpened a little)
     out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
-    _call("maavss_vit_attn", qkv.cuda().data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
+    qc = qkv.cuda()
+    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
     q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.float().split(384, 1)]
     p = (q @ k.transpose(-1, -2)).softmax(-1)
     want = (p @ v).transpose(1, 2).reshape(rows, 384)
     np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), rtol=2e-2, atol=8e-3)
     att = torch.empty(frames, 6, ntok - 1, device="cuda")
-    _call("maavss_vit_cls_attn", qkv.cuda().data_ptr(), att.data_ptr(), frames, ntok, 6, 1152, _st())
+    _call("maavss_vit_cls_attn", qc.data_ptr(), att.data_ptr(), frames, ntok, 6, 1152, _st())
     np.testing.assert_allclose(att.cpu().numpy(), p[:, :, 0, 1:].numpy(), rtol=1e-3, atol=1e-7)
 
 
@@ -97,7 +101,8 @@ def test_attn_maps_postprocess():
     att = torch.rand(f, 6, hp * wp, generator=torch.Generator().manual_seed(2))
     out = torch.empty(f, 1, hp * 8 + 4, wp * 8, device="cuda")
     ws = torch.empty(f * (hp * wp + 1), device="cuda")
-    _call("maavss_vit_attn_maps", att.cuda().data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8 + 4, wp * 8, 3, _st())
+    attc = att.cuda()
+    _call("maavss_vit_attn_maps", attc.data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8 + 4, wp * 8, 3, _st())
     want = torch.zeros(f, 1, hp * 8 + 4, wp * 8)
     for c in range(2):
         fr = vref.attention_frames_from_cls(att[3 * c:3 * c + 3], hp, wp)
