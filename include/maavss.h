@@ -87,7 +87,7 @@ int maavss_bn_stats_nblk(int64_t rows);
 int maavss_bn_stats(const float* y, float* partials, int64_t rows, int C, void* stream);
 int maavss_bn_finalize(const float* partials, int nblk, int C, double count, float eps, float momentum, float* mean,
                        float* invstd, float* running_mean, float* running_var, void* num_batches_tracked,
-                       void* stream);
+                       float* ws /* nullable; 256*2*C floats enable the two-level reduction */, void* stream);
 int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C, int pool,
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);

@@ -36,6 +36,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// level-1 reduction of many partial rows: block b sums rows [b*rpb, (b+1)*rpb) of [nblk][2C] into out[b][2C]
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                             int nblk, int C2, int rpb) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, idx = tid % C2, ph = tid / C2, nph = 256 / C2;
+  const int r0 = blockIdx.x * rpb, r1 = min(nblk, r0 + rpb);
+  double s = 0.0;
+  for (int r = r0 + ph; r < r1; r += nph) s += (double)partials[(int64_t)r * C2 + idx];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < C2) {
+    double a = 0.0;
+    for (int p = 0; p < nph; ++p) a += red[p * C2 + tid];
+    out[(int64_t)blockIdx.x * C2 + tid] = (float)a;
+  }
+}
+
 // one block; thread c reduces channel c over nblk partials in double.
 __global__ void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double count, float eps,
                                    float momentum, float* __restrict__ mean, float* __restrict__ invstd,
@@ -194,7 +211,7 @@ static PoolGeom make_geom(int B, int T, int H, int W, int C, int p, int64_t osB,
 
 extern "C" int maavss_bn_stats_nblk(int64_t rows) {
   int64_t n = (rows + 1023) / 1024;
-  if (n > 2048) n = 2048;
+  if (n > 512) n = 512;  // the finalize kernels walk the partial rows serially per channel
   if (n < 1) n = 1;
   return (int)n;
 }
@@ -211,8 +228,15 @@ extern "C" int maavss_bn_stats(const float* y, float* partials, int64_t rows, in
 
 extern "C" int maavss_bn_finalize(const float* partials, int nblk, int C, double count, float eps, float momentum,
                                   float* mean, float* invstd, float* running_mean, float* running_var,
-                                  void* num_batches_tracked, void* stream) {
+                                  void* num_batches_tracked, float* ws, void* stream) {
   MAAVSS_CHECK_ARG(partials && mean && invstd && nblk > 0 && C > 0 && C <= 64, "bn_finalize: bad arguments");
+  if (nblk > 512 && ws != nullptr) {  // two-level reduction: 256 blocks fold the partial rows first (ws: 256*2*C floats)
+    const int rpb = cdiv(nblk, 256), nb1 = cdiv(nblk, rpb);
+    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(nb1), dim3(256), 0, (hipStream_t)stream, partials, ws, nblk, 2 * C, rpb);
+    MAAVSS_LAUNCH_CHECK("bn_reduce_rows_kernel");
+    partials = ws;
+    nblk = nb1;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, C, count, eps, momentum,
                      mean, invstd, running_mean, running_var, (long long*)num_batches_tracked);
   MAAVSS_LAUNCH_CHECK("bn_finalize_kernel");

@@ -133,8 +133,9 @@ def bn_finalize(part, count, running_mean=None, running_var=None, num_batches_tr
     nblk, _, c = part.shape
     mean = torch.empty(c, device=part.device, dtype=torch.float32)
     invstd = torch.empty_like(mean)
+    ws = torch.empty(256 * 2 * c, device=part.device, dtype=torch.float32) if nblk > 512 else None
     call("maavss_bn_finalize", ptr(part), nblk, c, float(count), float(eps), float(momentum), ptr(mean), ptr(invstd),
-         ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), stream_ptr())
+         ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), ptr(ws), stream_ptr())
     return mean, invstd
 
 
