@@ -15,24 +15,28 @@
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partials,
                                                        int64_t M, int C, int rows_per_block) {
-  // thread -> channel c = tid % C, row phase tid / C; C is a power of two <= 64
-  __shared__ float red[2][256];
-  const int tid = threadIdx.x, c = tid % C, ph = tid / C, nph = 256 / C;
+  // thread -> 4 channels (c4 = tid % (C/4)), row phase tid / (C/4); C is a power of two in [4, 64]
+  __shared__ float4 red[2][256];
+  const int tid = threadIdx.x, C4 = C >> 2, c4 = tid % C4, ph = tid / C4, nph = 256 / C4;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float s1 = 0.f, s2 = 0.f;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   for (int64_t r = r0 + ph; r < r1; r += nph) {
-    const float v = y[r * C + c];
-    s1 += v;
-    s2 += v * v;
+    const float4 v = *reinterpret_cast<const float4*>(y + r * C + c4 * 4);
+    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
   }
   red[0][tid] = s1;
   red[1][tid] = s2;
   __syncthreads();
-  if (tid < C) {
-    float a = 0.f, b = 0.f;
-    for (int p = 0; p < nph; ++p) { a += red[0][p * C + tid]; b += red[1][p * C + tid]; }
-    partials[(int64_t)blockIdx.x * 2 * C + tid] = a;
-    partials[(int64_t)blockIdx.x * 2 * C + C + tid] = b;
+  if (tid < C4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int p = 0; p < nph; ++p) {
+      const float4 u = red[0][p * C4 + tid], w = red[1][p * C4 + tid];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+    }
+    *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.x * 2 * C + tid * 4) = a;
+    *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.x * 2 * C + C + tid * 4) = b;
   }
 }
 
@@ -89,28 +93,52 @@ __device__ __forceinline__ float act_bwd_from_out(float out, int act) {
   return act == ACT_TANH ? 1.f - out * out : (out > 0.f ? 1.f : 0.01f);
 }
 
+// every thread handles 4 consecutive channels of one (pooled) position: float4 traffic on the channels-last side
 __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, unsigned char* __restrict__ argmax,
                                                               PoolGeom g, int act) {
-  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * g.C;
+  const int C4 = g.C >> 2;
+  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % g.C);
-    const int64_t pos = i / g.C;
+    const int c = (int)(i % C4) * 4;
+    const int64_t pos = i / C4;
     const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
-    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
-    float best = -INFINITY;
-    int bi = 0;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c), mu = *reinterpret_cast<const float4*>(mean + c);
+    const float sc[4] = {ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w};
+    const float sh[4] = {be.x - mu.x * sc[0], be.y - mu.y * sc[1], be.z - mu.z * sc[2], be.w - mu.w * sc[3]};
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
     const float* yp = y + (((int64_t)bt * g.H + (int64_t)py * g.p) * g.W + (int64_t)px * g.p) * g.C + c;
     for (int dy = 0; dy < g.p; ++dy)
       for (int dx = 0; dx < g.p; ++dx) {
-        const float v = yp[((int64_t)dy * g.W + dx) * g.C] * sc + sh;
-        if (v > best || (v != v && best == best)) { best = v; bi = dy * g.p + dx; }
+        const float4 v4 = *reinterpret_cast<const float4*>(yp + ((int64_t)dy * g.W + dx) * g.C);
+        const float v[4] = {v4.x * sc[0] + sh[0], v4.y * sc[1] + sh[1], v4.z * sc[2] + sh[2], v4.w * sc[3] + sh[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (v[e] > best[e] || (v[e] != v[e] && best[e] == best[e])) { best[e] = v[e]; bi[e] = dy * g.p + dx; }
       }
     const int b = bt / g.T, t = bt % g.T;
-    out[b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC] = act_fwd(best, act);
-    if (argmax != nullptr) argmax[i] = (unsigned char)bi;
+    float* op = out + b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+    if (g.osC == 1) {
+      *reinterpret_cast<float4*>(op) = make_float4(act_fwd(best[0], act), act_fwd(best[1], act), act_fwd(best[2], act), act_fwd(best[3], act));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) op[e * g.osC] = act_fwd(best[e], act);
+    }
+    if (argmax != nullptr) *reinterpret_cast<uchar4*>(argmax + pos * g.C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+  }
+}
+
+__device__ __forceinline__ void load4_strided(const float* p, int64_t stride, float v[4]) {
+  if (stride == 1) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = p[e * stride];
   }
 }
 
@@ -118,32 +146,45 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
     const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ partials, PoolGeom g, int act, int64_t rows_per_block) {
-  // rows = pooled positions; thread -> (channel, row phase)
-  __shared__ float red[2][256];
-  const int tid = threadIdx.x, C = g.C, c = tid % C, ph = tid / C, nph = 256 / C;
+  // rows = pooled positions; thread -> (4 channels, row phase)
+  __shared__ float4 red[2][256];
+  const int tid = threadIdx.x, C = g.C, C4 = C >> 2, c = (tid % C4) * 4, ph = tid / C4, nph = 256 / C4;
   const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  const float mu = mean[c], is = invstd[c];
-  float s1 = 0.f, s2 = 0.f;
+  const float4 mu4 = *reinterpret_cast<const float4*>(mean + c), is4 = *reinterpret_cast<const float4*>(invstd + c);
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t pos = r0 + ph; pos < r1; pos += nph) {
     const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
     const int b = bt / g.T, t = bt % g.T;
     const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
-    const float gg = dout[oi] * act_bwd_from_out(out[oi], act);
-    const int bi = argmax != nullptr ? argmax[pos * C + c] : 0;
-    const int iy = py * g.p + bi / g.p, ix = px * g.p + bi % g.p;
-    const float xh = (y[(((int64_t)bt * g.H + iy) * g.W + ix) * C + c] - mu) * is;
-    s1 += gg;
-    s2 += gg * xh;
+    float dv[4], ov[4];
+    load4_strided(dout + oi, g.osC, dv);
+    load4_strided(out + oi, g.osC, ov);
+    uchar4 bi4 = make_uchar4(0, 0, 0, 0);
+    if (argmax != nullptr) bi4 = *reinterpret_cast<const uchar4*>(argmax + pos * C + c);
+    const int bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = dv[e] * act_bwd_from_out(ov[e], act);
+      const int iy = py * g.p + bi[e] / g.p, ix = px * g.p + bi[e] % g.p;
+      const float xh = (y[(((int64_t)bt * g.H + iy) * g.W + ix) * C + c + e] - mu[e]) * is[e];
+      s1[e] += gg;
+      s2[e] += gg * xh;
+    }
   }
-  red[0][tid] = s1;
-  red[1][tid] = s2;
+  red[0][tid] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  red[1][tid] = make_float4(s2[0], s2[1], s2[2], s2[3]);
   __syncthreads();
-  if (tid < C) {
-    float a = 0.f, b2 = 0.f;
-    for (int p = 0; p < nph; ++p) { a += red[0][p * C + tid]; b2 += red[1][p * C + tid]; }
-    partials[(int64_t)blockIdx.x * 2 * C + tid] = a;
-    partials[(int64_t)blockIdx.x * 2 * C + C + tid] = b2;
+  if (tid < C4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a;
+    for (int p = 0; p < nph; ++p) {
+      const float4 u = red[0][p * C4 + tid], w = red[1][p * C4 + tid];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
+    }
+    *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.x * 2 * C + tid * 4) = a;
+    *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.x * 2 * C + C + tid * 4) = b2;
   }
 }
 
@@ -172,31 +213,47 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_dx_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
     const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coef, float* __restrict__ dy, PoolGeom g, int act) {
-  const int C = g.C;
-  const int64_t total = (int64_t)g.BT * g.H * g.W * C;
+  const int C = g.C, C4 = C >> 2;
+  const int64_t total = (int64_t)g.BT * g.H * g.W * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const int64_t pos = i / C;
+    const int c = (int)(i % C4) * 4;
+    const int64_t pos = i / C4;
     const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), bt = (int)(pos / ((int64_t)g.W * g.H));
     const int py = iy / g.p, px = ix / g.p;
-    float gg = 0.f;
+    float gg[4] = {0.f, 0.f, 0.f, 0.f};
     if (py < g.Hp && px < g.Wp) {
       const int64_t ppos = ((int64_t)bt * g.Hp + py) * g.Wp + px;
-      const int bi = argmax != nullptr ? argmax[ppos * C + c] : 0;
-      if (bi == (iy - py * g.p) * g.p + (ix - px * g.p)) {
+      const int here = (iy - py * g.p) * g.p + (ix - px * g.p);
+      uchar4 bi4 = make_uchar4(0, 0, 0, 0);
+      if (argmax != nullptr) bi4 = *reinterpret_cast<const uchar4*>(argmax + ppos * C + c);
+      const int bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+      if (bi[0] == here || bi[1] == here || bi[2] == here || bi[3] == here) {
         const int b = bt / g.T, t = bt % g.T;
         const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
-        gg = dout[oi] * act_bwd_from_out(out[oi], act);
+        float dv[4], ov[4];
+        load4_strided(dout + oi, g.osC, dv);
+        load4_strided(out + oi, g.osC, ov);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (bi[e] == here) gg[e] = dv[e] * act_bwd_from_out(ov[e], act);
       }
     }
-    const float xh = (y[i] - mean[c]) * invstd[c];
-    dy[i] = coef[c] * (gg - coef[C + c] - xh * coef[2 * C + c]);
+    const float4 yv = *reinterpret_cast<const float4*>(y + pos * C + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 k0 = *reinterpret_cast<const float4*>(coef + c), k1 = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    float4 o;
+    o.x = k0.x * (gg[0] - k1.x - (yv.x - mu.x) * is.x * k2.x);
+    o.y = k0.y * (gg[1] - k1.y - (yv.y - mu.y) * is.y * k2.y);
+    o.z = k0.z * (gg[2] - k1.z - (yv.z - mu.z) * is.z * k2.z);
+    o.w = k0.w * (gg[3] - k1.w - (yv.w - mu.w) * is.w * k2.w);
+    *reinterpret_cast<float4*>(dy + pos * C + c) = o;
   }
 }
 
 static int check_geom(const char* who, int B, int T, int H, int W, int C, int p) {
   MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "%s: empty tensor", who);
-  MAAVSS_CHECK_ARG(C >= 1 && C <= 64 && (C & (C - 1)) == 0, "%s: C must be a power of two <= 64 (got %d)", who, C);
+  MAAVSS_CHECK_ARG(C >= 4 && C <= 64 && (C & (C - 1)) == 0, "%s: C must be a power of two in [4, 64] (got %d)", who, C);
   MAAVSS_CHECK_ARG(p >= 1 && p <= 3, "%s: pool must be 1, 2 or 3", who);
   MAAVSS_CHECK_ARG(H / p > 0 && W / p > 0, "%s: pooled size is zero", who);
   return MAAVSS_OK;
@@ -218,7 +275,7 @@ extern "C" int maavss_bn_stats_nblk(int64_t rows) {
 
 extern "C" int maavss_bn_stats(const float* y, float* partials, int64_t rows, int C, void* stream) {
   MAAVSS_CHECK_ARG(y && partials && rows > 0, "bn_stats: bad arguments");
-  MAAVSS_CHECK_ARG(C >= 1 && C <= 64 && (C & (C - 1)) == 0, "bn_stats: C must be a power of two <= 64");
+  MAAVSS_CHECK_ARG(C >= 4 && C <= 64 && (C & (C - 1)) == 0, "bn_stats: C must be a power of two in [4, 64]");
   const int nblk = maavss_bn_stats_nblk(rows);
   const int rpb = cdiv(rows, nblk);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, partials, rows, C, rpb);
@@ -251,7 +308,7 @@ extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const f
   if (int rc = check_geom("bn_pool_act_fwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_fwd: argmax buffer required when pool > 1");
   PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
-  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C;
+  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * (C / 4);
   hipLaunchKernelGGL(bn_pool_act_fwd_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, g, act);
   MAAVSS_LAUNCH_CHECK("bn_pool_act_fwd_kernel");
@@ -279,7 +336,7 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, ws, nblk, C, count, gamma, invstd, dgamma, dbeta,
                      accumulate, coef);
   MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_kernel");
-  const int64_t total = (int64_t)g.BT * H * W * C;
+  const int64_t total = (int64_t)g.BT * H * W * (C / 4);
   hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
                      (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);
   MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");

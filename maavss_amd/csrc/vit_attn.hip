@@ -2,141 +2,184 @@
 // attention of the last block -- what dino's Attention.forward / get_last_selfattention compute for the
 // reference's video_attention.py:52-56.
 //
-// vit_attn_kernel: flash-style, never materialises the N x N scores.  Workgroup = 64 query rows of one
-// (frame, head); each of the 4 waves owns 16 rows.  K/V tiles of 64 keys are staged in LDS (K XOR-swizzled for
-// ds_read_b128, V row-major for ds_read_b64_tr_b16); S = Q K^T and O += P V run on v_mfma_f32_16x16x32_bf16;
-// the online softmax (running max / sum per query row) uses 16-lane shuffles; P goes through a per-wave LDS
-// tile to become the A operand of P V.  qkv is the fused projection output [rows][1152] (q already scaled by
-// 1/8 in the GEMM epilogue), out is [rows][384] with heads concatenated, both bf16.
+// vit_attn_kernel: flash-style, never materialises the N x N scores.  Workgroup = 128 query rows of one
+// (frame, head); each of the 4 waves owns 32 rows (two 16-row tiles).  Per 64-key tile:
+//   S^T = K Q^T  on v_mfma_f32_16x16x32_bf16 with K as the A operand: the accumulator then has the QUERY on the
+//         lane and 16 keys in registers, so the softmax row maximum is a register reduction plus two cross-lane
+//         exchanges (lanes l, l^16, l^32, l^48), and
+//   O^T += V^T P^T takes the exponentiated accumulator, packed to bf16, DIRECTLY as its B operand (the MFMA k
+//         slot (g, e) is assigned to key 32*ks + 16*(e>>2) + 4*g + (e&3), and V^T fragments are read with the same
+//         assignment by ds_read_b64_tr_b16) -- P never goes through LDS.
+// K/V tiles are double-buffered in LDS (K XOR-swizzled per 16-B chunk for ds_read_b128, V per 32-B granule for
+// the transposed reads); the next tile's global loads are issued before the MFMAs and written after them.
+// qkv is the fused projection output [rows][1152] bf16 with q pre-scaled by log2(e)/8 in the GEMM epilogue
+// (softmax runs on exp2); out is [rows][384] bf16 with heads concatenated.
 // vit_cls_attn_kernel: last block only -- the CLS query against all keys, softmax over N tokens, the CLS
 // column dropped (video_attention.py:56): att [frames][6][N-1] f32.
 #include "mma.h"
 
 #define ATT_D 64
-#define ATT_QT 64
+#define ATT_QT 128
 #define ATT_KT 64
-#define P_LD 72  // bf16 elements per P row in LDS (144 B: 16-B aligned)
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok,
                                                        int ld_qkv, int ld_out, int dim) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_D];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[ATT_KT * ATT_D];
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[4 * 16 * P_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2][ATT_KT * ATT_D];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[2][ATT_KT * ATT_D];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, gq = lane >> 4;
-  const int q0 = blockIdx.x * ATT_QT, head = blockIdx.y, frame = blockIdx.z;
+  const int q0 = blockIdx.x * ATT_QT + wv * 32, head = blockIdx.y, frame = blockIdx.z;
   const int64_t row0 = (int64_t)frame * ntok;
   const bf16_t* qbase = qkv + head * ATT_D;
   const bf16_t* kbase = qkv + dim + head * ATT_D;
   const bf16_t* vbase = qkv + 2 * dim + head * ATT_D;
 
-  // Q fragments of this wave's 16 rows (rows past the end are clamped; their results are never stored)
-  bf16x8 fq[2];
-  {
-    int qr = q0 + wv * 16 + l16;
-    qr = qr < ntok ? qr : ntok - 1;
+  // Q^T fragments (B operand): lane (q = l16, gq) holds Q[q][32 ks + 8 gq .. +7]
+  bf16x8 fq[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int qr = q0 + t * 16 + l16;
+    qr = qr < ntok ? qr : ntok - 1;  // rows past the end are clamped; their results are never stored
     const bf16_t* qp = qbase + (row0 + qr) * ld_qkv;
-    fq[0] = *reinterpret_cast<const bf16x8*>(qp + gq * 8);
-    fq[1] = *reinterpret_cast<const bf16x8*>(qp + 32 + gq * 8);
+    fq[t][0] = *reinterpret_cast<const bf16x8*>(qp + gq * 8);
+    fq[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + gq * 8);
   }
-  f32x4 o[4];
+  f32x4 o[2][4];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[4], lrow[4];
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
-  bf16_t* pw = Ps + wv * 16 * P_LD;
+    for (int d = 0; d < 4; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
 
-  for (int kv0 = 0; kv0 < ntok; kv0 += ATT_KT) {
-    __syncthreads();
-    // stage K (swizzled) and V tiles: 64 keys x 128 B each, 16-B chunks
+  // staging map: thread -> (key = idx>>3, 16-B chunk c = idx&7) for idx = tid and tid + 256
+  uint4 kreg[2], vreg[2];
+  auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int q = it * 256 + tid, key = q >> 3, c = q & 7;
-      uint4 kvv = make_uint4(0, 0, 0, 0), vvv = make_uint4(0, 0, 0, 0);
+      const int idx = it * 256 + tid, key = idx >> 3, c = idx & 7;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      vreg[it] = make_uint4(0, 0, 0, 0);
       if (kv0 + key < ntok) {
-        kvv = *reinterpret_cast<const uint4*>(kbase + (row0 + kv0 + key) * ld_qkv + c * 8);
-        vvv = *reinterpret_cast<const uint4*>(vbase + (row0 + kv0 + key) * ld_qkv + c * 8);
+        kreg[it] = *reinterpret_cast<const uint4*>(kbase + (row0 + kv0 + key) * ld_qkv + c * 8);
+        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (row0 + kv0 + key) * ld_qkv + c * 8);
       }
-      *reinterpret_cast<uint4*>(Ks + key * ATT_D + ((c ^ (key & 7)) * 8)) = kvv;
-      *reinterpret_cast<uint4*>(Vs + key * ATT_D + c * 8) = vvv;
     }
-    __syncthreads();
-    // S = Q K^T  (16 rows x 64 keys per wave)
-    f32x4 s[4];
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 256 + tid, key = idx >> 3, c = idx & 7;
+      *reinterpret_cast<uint4*>(&Ks[buf][key * ATT_D + ((c ^ (key & 7)) * 8)]) = kreg[it];
+      *reinterpret_cast<uint4*>(&Vs[buf][key * ATT_D + (((c >> 1) ^ ((key >> 1) & 3)) * 16) + (c & 1) * 8]) = vreg[it];
+    }
+  };
+
+  const int ntiles = (ntok + ATT_KT - 1) / ATT_KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1, kv0 = kt * ATT_KT;
+    if (kt + 1 < ntiles) load_tile(kv0 + ATT_KT);
+    // ---- S^T = K Q^T : s[t][nt][r] = score(key 16 nt + 4 gq + r, query t*16 + l16)
+    f32x4 s[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[0][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[1][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int key = nt * 16 + l16;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(Ks + key * ATT_D + (((ks * 4 + gq) ^ (key & 7)) * 8));
-        Mma<MODE_BF16>::mma(s[nt], fq[ks], fk);
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&Ks[buf][key * ATT_D + (((ks * 4 + gq) ^ (key & 7)) * 8)]);
+        Mma<MODE_BF16>::mma(s[0][nt], fk, fq[0][ks]);
+        Mma<MODE_BF16>::mma(s[1][nt], fk, fq[1][ks]);
       }
-      if (kv0 + key >= ntok) s[nt] = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
     }
-    // online softmax: row (4*gq + r) lives in the 16 lanes that share gq
-    float alpha[4];
+    if (kv0 + ATT_KT > ntok) {  // last, partial tile: mask the padded keys
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float mx = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      const float mn = fmaxf(mrow[r], mx);
-      alpha[r] = __expf(mrow[r] - mn);
-      mrow[r] = mn;
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + nt * 16 + gq * 4 + r >= ntok) { s[0][nt][r] = -1e30f; s[1][nt][r] = -1e30f; }
+    }
+    // ---- online softmax (base 2), query on the lane
+    bf16x8 fp[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float mx = s[t][0][0];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][nt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(mrow[t], mx);
+      const float alpha = fast_exp2(mrow[t] - mn);
+      mrow[t] = mn;
       float sum = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const float p = __expf(s[nt][r] - mn);
-        s[nt][r] = p;
-        sum += p;
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(s[t][nt][r] - mn);
+          s[t][nt][r] = p;
+          sum += p;
+        }
+      lrow[t] = lrow[t] * alpha + sum;  // per-lane partial; the 4 lanes of a query are summed at the end
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned w0 = pack_bf2(s[t][2 * ks][0], s[t][2 * ks][1]), w1 = pack_bf2(s[t][2 * ks][2], s[t][2 * ks][3]);
+        const unsigned w2 = pack_bf2(s[t][2 * ks + 1][0], s[t][2 * ks + 1][1]), w3 = pack_bf2(s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
+        const uint4 u = make_uint4(w0, w1, w2, w3);
+        fp[t][ks] = __builtin_bit_cast(bf16x8, u);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
-      lrow[r] = lrow[r] * alpha[r] + sum;
     }
+    // ---- O^T += V^T P^T : o[t][dt][r] = O(query t*16 + l16, d = 16 dt + 4 gq + r)
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[d][r] *= alpha[r];
-    // P -> LDS (C layout -> A operand layout)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pw[(gq * 4 + r) * P_LD + nt * 16 + l16] = f2bf(s[nt][r]);
-    __syncthreads();
-    // O += P V
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 fp = *reinterpret_cast<const bf16x8*>(pw + l16 * P_LD + ks * 32 + gq * 8);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int dt = 0; dt < 4; ++dt) {
         bf16x4 h[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const int key = ks * 32 + gq * 8 + hh * 4 + (l16 >> 2);
-          const bf16_t* a = Vs + key * ATT_D + d * 16 + (l16 & 3) * 4;
+          const int key = ks * 32 + hh * 16 + gq * 4 + (l16 >> 2);
+          const bf16_t* a = &Vs[buf][key * ATT_D + ((dt ^ ((key >> 1) & 3)) * 16) + (l16 & 3) * 4];
           h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
         }
         const bf16x8 fv = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-        Mma<MODE_BF16>::mma(o[d], fp, fv);
+        Mma<MODE_BF16>::mma(o[0][dt], fv, fp[0][ks]);
+        Mma<MODE_BF16>::mma(o[1][dt], fv, fp[1][ks]);
       }
-    }
+    if (kt + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
   }
-  // normalise and store
+  // ---- normalise and store: lane holds d = 16 dt + 4 gq + (0..3) of its query
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qr = q0 + wv * 16 + gq * 4 + r;
+  for (int t = 0; t < 2; ++t) {
+    float l = lrow[t];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int qr = q0 + t * 16 + l16;
     if (qr < ntok) {
-      const float inv = 1.f / lrow[r];
-      bf16_t* op = out + (row0 + qr) * ld_out + head * ATT_D;
+      bf16_t* op = out + (row0 + qr) * ld_out + head * ATT_D + gq * 4;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) op[d * 16 + l16] = f2bf(o[d][r] * inv);
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 u;
+        u.x = pack_bf2(o[t][dt][0] * inv, o[t][dt][1] * inv);
+        u.y = pack_bf2(o[t][dt][2] * inv, o[t][dt][3] * inv);
+        *reinterpret_cast<uint2*>(op + dt * 16) = u;
+      }
     }
   }
 }
 
-// one block per (frame, head): scores of the CLS query against all tokens
+// one block per (frame, head): scores of the CLS query against all tokens (q pre-scaled by log2(e)/8 -> exp2)
 __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ att, int ntok,
                                                            int ld_qkv, int dim) {
   extern __shared__ float sc[];  // [ntok]
@@ -170,7 +213,7 @@ __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restr
   __syncthreads();
   float sum = 0.f;
   for (int j = tid; j < ntok; j += 256) {
-    const float p = __expf(sc[j] - mx);
+    const float p = exp2f(sc[j] - mx);
     sc[j] = p;
     sum += p;
   }
@@ -185,7 +228,8 @@ __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restr
 extern "C" int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out,
                                void* stream) {
   MAAVSS_CHECK_ARG(qkv && out && frames > 0 && ntok > 0, "vit_attn: bad arguments");
-  MAAVSS_CHECK_ARG(heads >= 1 && ld_qkv >= 3 * heads * ATT_D && ld_out >= heads * ATT_D && ld_qkv % 8 == 0, "vit_attn: bad layout");
+  MAAVSS_CHECK_ARG(heads >= 1 && ld_qkv >= 3 * heads * ATT_D && ld_out >= heads * ATT_D && ld_qkv % 8 == 0 && ld_out % 4 == 0,
+                   "vit_attn: bad layout");
   hipLaunchKernelGGL(vit_attn_kernel, dim3(cdiv(ntok, ATT_QT), heads, frames), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, (bf16_t*)out, ntok, ld_qkv, ld_out, heads * ATT_D);
   MAAVSS_LAUNCH_CHECK("vit_attn_kernel");

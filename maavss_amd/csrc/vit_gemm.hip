@@ -5,20 +5,27 @@
 //
 //   C[M,N] = epilogue( A[M,K] (bf16, row-major) . W[N,K]^T (bf16, torch Linear layout) )
 //
-// 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles),
-// BK = 64.  Operand tiles go global -> LDS directly (global_load_lds, 16 B per lane), double-buffered; the
-// LDS image is lane-linear, so the bank-conflict swizzle (16-B chunk ^= row & 7) is applied to the per-lane
-// SOURCE address and again on the ds_read_b128 side.  Blocks are remapped so that the N-tiles of one M-panel
-// run on the same XCD (A panel re-read from that XCD's L2, not from HBM).
-// Epilogues: +bias (and 1/8 on the q third) -> bf16 | +bias, exact-erf GELU -> bf16 | +bias +residual -> f32
-// (in place on the residual stream) | + periodic row table (conv bias / cls token + position embedding) -> f32.
-// bf16 outputs are staged through LDS and stored as full 256-byte rows.
+// 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles), BK = 32.
+// These GEMMs have SHORT K (384 / 1536 / 192), so the cost is latency per tile, not steady-state issue:
+//   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 4-slot ring; three
+//     K-steps stay in flight across a raw s_barrier behind a counted s_waitcnt vmcnt (never 0 in the loop);
+//   * 64 KiB of LDS per workgroup -> two workgroups per CU overlap each other's prologue / epilogue;
+//   * the LDS image is lane-linear, so the bank swizzle (16-B chunk ^= (row>>2)&2, conflict-free for the
+//     ds_read_b128 lane groups on 64-B rows) is applied to the per-lane SOURCE address and again on the read;
+//   * blocks are remapped so that the N-tiles of one M-panel run on the same XCD (A panel from that L2).
+// Epilogues: +bias (and 1/8 on the q third) -> bf16 | +bias, GELU -> bf16 | +bias +residual -> f32 (in place
+// on the residual stream) | + periodic row table (conv bias / cls token + position embedding) -> f32.
+// All outputs are staged through LDS and written as full rows (16 B per lane).
 #include "mma.h"
 
 #define EPI_BF16_BIAS 0
 #define EPI_BF16_BIAS_GELU 1
 #define EPI_F32_BIAS_RESID 2
 #define EPI_F32_ROWTABLE 3
+
+#define VG_BK 32
+#define VG_STAGES 4
+#define VG_STAGE_ELEMS (2 * 128 * VG_BK)  // A tile + B tile, bf16 elements
 
 struct VGemmArgs {
   const bf16_t* A;
@@ -38,14 +45,22 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below the bf16 output rounding)
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.f - poly * __expf(-x * x);
+  const float erf_v = v < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * v * (1.f + erf_v);
+}
+
 template <int EPI>
-__global__ __launch_bounds__(256) void vit_gemm_kernel(VGemmArgs g) {
+__global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [2 buffers][A 128x64 | B 128x64] bf16 = 2 * 32 KiB ; epilogue reuses it as a [128][136] bf16 image
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [4 stages][A 128x32 | B 128x32] bf16 = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
-  // XCD-aware remap: consecutive ids of one XCD walk the N tiles of the same M panel.
   const int nwg = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
   {
@@ -55,19 +70,26 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VGemmArgs g) {
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * 128, n0 = tn * 128;
 
-  // staging: one wave-instruction = 8 rows x 128 B; wave wv stages rows [wv*32, wv*32+32) of A and of B.
-  const int srow = lane >> 3, schunk = lane & 7;
-  auto stage = [&](int kt, int buf) {
-    bf16_t* la = lds + buf * (2 * 128 * 64);
-    bf16_t* lb = la + 128 * 64;
+  // staging: one wave-instruction = 16 rows x 64 B; wave wv stages rows [wv*32, wv*32+32) of A and of B.
+  const int srow = lane >> 2, sslot = lane & 3;
+  const bf16_t* asrc[2];
+  const bf16_t* bsrc[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = wv * 32 + i * 8 + srow;
-      const int gc = schunk ^ (r & 7);
-      int ar = m0 + r;
-      ar = ar < g.M ? ar : g.M - 1;
-      glds16(g.A + (int64_t)ar * g.lda + kt * 64 + gc * 8, la + (wv * 32 + i * 8) * 64 + lane * 8);
-      glds16(g.W + (int64_t)(n0 + r) * g.K + kt * 64 + gc * 8, lb + (wv * 32 + i * 8) * 64 + lane * 8);
+  for (int i = 0; i < 2; ++i) {
+    const int r = wv * 32 + i * 16 + srow;
+    const int gc = sslot ^ ((r >> 2) & 2);
+    int ar = m0 + r;
+    ar = ar < g.M ? ar : g.M - 1;
+    asrc[i] = g.A + (int64_t)ar * g.lda + gc * 8;
+    bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + gc * 8;
+  }
+  auto stage = [&](int kt) {
+    bf16_t* la = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
+    bf16_t* lb = la + 128 * VG_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(asrc[i] + kt * VG_BK, la + (wv * 32 + i * 16) * VG_BK + lane * 8);
+      glds16(bsrc[i] + kt * VG_BK, lb + (wv * 32 + i * 16) * VG_BK + lane * 8);
     }
   };
 
@@ -77,38 +99,41 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / 64;
-  stage(0, 0);
-  __syncthreads();  // drains vmcnt(0) too
+  const int nk = g.K / VG_BK;  // >= 3 (checked by the launcher)
+  stage(0);
+  stage(1);
+  stage(2);
   const int l16 = lane & 15, gq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-    const bf16_t* la = lds + buf * (2 * 128 * 64);
-    const bf16_t* lb = la + 128 * 64;
+    // stage kt must have landed: each wave issued 4 loads per stage; stages kt+1, kt+2 may stay in flight.
+    const int ahead = nk - 1 - kt;  // stages issued beyond kt
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's part of stage kt is in LDS; every wave is done with stage kt-1
+    if (kt + 3 < nk) stage(kt + 3); // refills the slot that held stage kt-1
+    const bf16_t* la = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
+    const bf16_t* lb = la + 128 * VG_BK;
+    bf16x8 fa[4], fb[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + l16;
-        fa[i] = *reinterpret_cast<const bf16x8*>(la + r * 64 + (((s * 4 + gq) ^ (r & 7)) * 8));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wn * 64 + j * 16 + l16;
-        fb[j] = *reinterpret_cast<const bf16x8*>(lb + r * 64 + (((s * 4 + gq) ^ (r & 7)) * 8));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Mma<MODE_BF16>::mma(acc[i][j], fa[i], fb[j]);
+    for (int i = 0; i < 4; ++i) {
+      const int r = wm * 64 + i * 16 + l16;
+      fa[i] = *reinterpret_cast<const bf16x8*>(la + r * VG_BK + ((gq ^ ((r >> 2) & 2)) * 8));
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wn * 64 + j * 16 + l16;
+      fb[j] = *reinterpret_cast<const bf16x8*>(lb + r * VG_BK + ((gq ^ ((r >> 2) & 2)) * 8));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Mma<MODE_BF16>::mma(acc[i][j], fa[i], fb[j]);
   }
+  __syncthreads();  // all waves done reading the ring before the epilogue reuses it
 
   if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
-    constexpr int LDC = 136;  // bf16 elements per staged row (272 B: 16-B aligned, breaks the 256-B bank period)
+    constexpr int LDC = 136;  // bf16 elements per staged row (272 B)
     bf16_t* cs = lds;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -121,7 +146,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + bv;
-          if constexpr (EPI == EPI_BF16_BIAS_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+          if constexpr (EPI == EPI_BF16_BIAS_GELU) v = gelu_erf(v);
           else v *= sc;
           cs[(wm * 64 + i * 16 + gq * 4 + r) * LDC + nl] = f2bf(v);
         }
@@ -136,22 +161,40 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VGemmArgs g) {
             *reinterpret_cast<const uint4*>(cs + row * LDC + c16 * 8);
     }
   } else {
+    // f32 outputs: two passes of 64 rows through a [64][132] f32 LDS image, then float4 read-modify-write rows
+    constexpr int LDF = 132;
+    float* cf = reinterpret_cast<float*>(smem);
     float* C = reinterpret_cast<float*>(g.C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int half = 0; half < 2; ++half) {
+      if (half) __syncthreads();
+      if (wm == half) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + gq * 4 + r;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cf[(i * 16 + gq * 4 + r) * LDF + wn * 64 + j * 16 + l16] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = it * 256 + tid, row = q >> 5, c4 = (q & 31) * 4;
+        const int m = m0 + half * 64 + row;
         if (m < g.M) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l16;
-            float* c = C + (int64_t)m * g.ldc + n;
-            if constexpr (EPI == EPI_F32_BIAS_RESID) *c = *c + acc[i][j][r] + g.bias[n];
-            else *c = acc[i][j][r] + g.table[(int64_t)(m % g.period) * g.N + n];
+          const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
+          float4* cp = reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n0 + c4);
+          float4 add;
+          if constexpr (EPI == EPI_F32_BIAS_RESID) {
+            const float4 res = *cp, bb = *reinterpret_cast<const float4*>(g.bias + n0 + c4);
+            add = make_float4(res.x + bb.x, res.y + bb.y, res.z + bb.z, res.w + bb.w);
+          } else {
+            add = *reinterpret_cast<const float4*>(g.table + (int64_t)(m % g.period) * g.N + n0 + c4);
           }
+          *cp = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
         }
       }
+    }
   }
 }
 
@@ -159,7 +202,7 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
                                void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
                                void* stream) {
   MAAVSS_CHECK_ARG(A && W && C && M > 0, "vit_gemm: bad arguments");
-  MAAVSS_CHECK_ARG(N % 128 == 0 && K % 64 == 0 && K >= 64, "vit_gemm: N must be a multiple of 128 and K of 64 (N=%d K=%d)", N, K);
+  MAAVSS_CHECK_ARG(N % 128 == 0 && K % VG_BK == 0 && K >= 3 * VG_BK, "vit_gemm: N must be a multiple of 128 and K of 32, K >= 96 (N=%d K=%d)", N, K);
   MAAVSS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0, "vit_gemm: leading dimensions must be multiples of 8");
   MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "vit_gemm: unknown epilogue");
   MAAVSS_CHECK_ARG(epilogue == EPI_F32_ROWTABLE ? (table && period > 0) : (bias != nullptr), "vit_gemm: missing bias/table");
@@ -170,7 +213,7 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   g.qscale_cols = qscale_cols; g.qscale = qscale;
   g.tiles_n = N / 128; g.tiles_m = cdiv(M, 128);
   const dim3 grid(g.tiles_n * g.tiles_m), block(256);
-  const size_t smem = 2 * 2 * 128 * 64 * sizeof(bf16_t);
+  const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 64 KiB
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case EPI_BF16_BIAS: hipLaunchKernelGGL(vit_gemm_kernel<EPI_BF16_BIAS>, grid, block, smem, st, g); break;

@@ -181,7 +181,7 @@ class VideoAttention:
             b = wts[i]
             call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
             call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
-                 3 * DIM, DIM, EPI_BF16_BIAS, DIM, 0.125, st)
+                 3 * DIM, DIM, EPI_BF16_BIAS, DIM, 0.125 * 1.4426950408889634, st)   # q *= log2(e)/sqrt(64): exp2 softmax
             if i == DEPTH - 1:
                 break
             call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, st)

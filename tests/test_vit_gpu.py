@@ -82,12 +82,12 @@ def test_vit_layernorm_and_patchify():
 def test_vit_attention_and_cls(ntok, frames):
     rows = frames * ntok
     qkv = bf(rnd(rows, 1152, seed=1, scale=1.0))
-    qkv[:, :384] *= 0.125 * 3                                  # q already carries the 1/8 scale (sharpened a little)
+    qkv[:, :384] *= 0.125 * 3 * 1.4426950408889634             # kernel contract: q carries log2(e)/8 (softmax on exp2)
     out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
     qc = qkv.cuda()
     _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
     q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.float().split(384, 1)]
-    p = (q @ k.transpose(-1, -2)).softmax(-1)
+    p = ((q @ k.transpose(-1, -2)) * 0.6931471805599453).softmax(-1)      # 2^(q.k) normalised
     want = (p @ v).transpose(1, 2).reshape(rows, 384)
     np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), rtol=2e-2, atol=8e-3)
     att = torch.empty(frames, 6, ntok - 1, device="cuda")
