@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--precise", action="store_true", help="exact-f32 MFMA in the fusion network (parity mode)")
+    ap.add_argument("--verbose", action="store_true", help="per-shape kernel table on stderr")
+    ap.add_argument("--vit-chunk", type=int, default=0, help="frames per ViT launch group (0 = library default)")
     return ap.parse_args()
 
 
@@ -149,6 +151,8 @@ def main():
     frames, audio = synthetic_inputs(torch, b, t, w, length, 1234 + rank, dev)
 
     va = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth", device=dev)   # random init: no network
+    if args.vit_chunk:
+        va.frames_per_launch = args.vit_chunk
     stft = maavss_amd.STFT(args.fft_len, hop, noise_std=0.1, device=dev)
     try:
         model = maavss_amd.AV_Fusion_Model_Frames([b, 2, t_a, n_bins], [b, 1, t, w, w], hpf, precise=args.precise)
@@ -215,6 +219,19 @@ def main():
                             "share_of_kernel_time": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3)}
                 break
         breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:12]}
+        if args.verbose:
+            shapes = {}
+            for name, a, e0, e1 in timer.records:
+                if name == "maavss_vit_gemm":
+                    key = f"vit_gemm epi{a[11]} M{a[8]} N{a[9]} K{a[10]}"
+                    d = shapes.setdefault(key, [0, 0.0, 0.0])
+                    d[0] += 1
+                    d[1] += e0.elapsed_time(e1)
+                    d[2] += 2.0 * a[8] * a[9] * a[10]
+            for key, (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                print(f"[bench] {key}: {n} launches, {ms / n * 1e3:.1f} us avg, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
+            print(f"[bench] sum of kernel time {sum(v['ms'] for v in summ.values()) / args.steps:.2f} ms/step, "
+                  f"wall {elapsed / args.steps * 1e3:.2f} ms/step, {len(timer.records) // args.steps} launches/step", file=sys.stderr)
         with open(os.path.join(ROOT, "BASELINE.json")) as fh:
             metric = json.load(fh)["metric"]
         clips = b * world * args.steps
