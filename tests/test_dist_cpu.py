@@ -1,0 +1,69 @@
+"""CPU (gloo, world_size 2) tests of the data-parallel plumbing: batch sharding and the gradient all-reduce
+(GradSync) that TrainStep runs over RCCL on the GPUs.  The collective code path is backend-agnostic, so gloo
+exercises exactly what "nccl" (= RCCL) runs."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maavss_amd.trainer import GradSync, shard_batch
+    n, fusion_end = 1000, 640
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    sync = GradSync(g, fusion_end)
+    assert sync.enabled and sync.world == world
+    sync.start_fusion()              # large segment first (overlaps the encoder backward on the GPU)
+    g[fusion_end:] += 0.0            # "encoder backward still running"
+    sync.finish()
+    want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    assert torch.equal(g, want), (rank, (g - want).abs().max())
+    # a second step re-uses the object
+    g.copy_(torch.ones(n) * (rank + 2))
+    sync.finish()
+    assert torch.equal(g, torch.ones(n) * sum(r + 2 for r in range(world)))
+    lo, hi = shard_batch(37, rank, world)
+    torch.save({"lo": lo, "hi": hi}, os.path.join(out_dir, f"shard_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_and_sharding_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    shards = [torch.load(os.path.join(tmp_path, f"shard_{r}.pt"), weights_only=True) for r in range(world)]
+    assert shards[0]["lo"] == 0 and shards[-1]["hi"] == 37
+    assert all(shards[r]["hi"] == shards[r + 1]["lo"] for r in range(world - 1))
+    sizes = [s["hi"] - s["lo"] for s in shards]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_batch_covers_everything():
+    from maavss_amd.trainer import shard_batch
+    for world in (1, 2, 4, 8):
+        for batch in (8, 32, 37, 256):
+            spans = [shard_batch(batch, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_gradsync_noop_single_process():
+    from maavss_amd.trainer import GradSync
+    g = torch.ones(10)
+    s = GradSync(g, 5)
+    assert not s.enabled and s.world == 1
+    s.start_fusion()
+    s.finish()
+    assert torch.equal(g, torch.ones(10))
