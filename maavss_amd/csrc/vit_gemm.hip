@@ -7,9 +7,11 @@
 //
 // 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles), BK = 32.
 // These GEMMs have SHORT K (384 / 1536 / 192), so the cost is latency per tile, not steady-state issue:
-//   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 4-slot ring; three
+//   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 5-slot ring; up to three
 //     K-steps stay in flight across a raw s_barrier behind a counted s_waitcnt vmcnt (never 0 in the loop);
-//   * 64 KiB of LDS per workgroup -> two workgroups per CU overlap each other's prologue / epilogue;
+//   * the LDS fragment reads of K-step kt+1 are issued BEFORE the 16 MFMAs of K-step kt (two named fragment
+//     sets, loop unrolled by two), so LDS latency hides under the matrix pipe instead of in front of it;
+//   * 80 KiB of LDS per workgroup -> two workgroups per CU overlap each other's prologue / epilogue;
 //   * the LDS image is lane-linear, so the bank swizzle (16-B chunk ^= (row>>2)&2, conflict-free for the
 //     ds_read_b128 lane groups on 64-B rows) is applied to the per-lane SOURCE address and again on the read;
 //   * blocks are remapped so that the N-tiles of one M-panel run on the same XCD (A panel from that L2).
@@ -24,7 +26,7 @@
 #define EPI_F32_ROWTABLE 3
 
 #define VG_BK 32
-#define VG_STAGES 4
+#define VG_STAGES 5
 #define VG_STAGE_ELEMS (2 * 128 * VG_BK)  // A tile + B tile, bf16 elements
 
 struct VGemmArgs {
@@ -99,37 +101,64 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / VG_BK;  // >= 3 (checked by the launcher)
-  stage(0);
-  stage(1);
-  stage(2);
+  const int nk = g.K / VG_BK;  // >= 4 (checked by the launcher)
   const int l16 = lane & 15, gq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed: each wave issued 4 loads per stage; stages kt+1, kt+2 may stay in flight.
-    const int ahead = nk - 1 - kt;  // stages issued beyond kt
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave's part of stage kt is in LDS; every wave is done with stage kt-1
-    if (kt + 3 < nk) stage(kt + 3); // refills the slot that held stage kt-1
-    const bf16_t* la = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
-    const bf16_t* lb = la + 128 * VG_BK;
-    bf16x8 fa[4], fb[4];
+  // per-lane fragment offsets inside a stage (swizzled), constant over the K loop
+  int offa[4], offb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = wm * 64 + i * 16 + l16;
-      fa[i] = *reinterpret_cast<const bf16x8*>(la + r * VG_BK + ((gq ^ ((r >> 2) & 2)) * 8));
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + l16, rb = wn * 64 + i * 16 + l16;
+    offa[i] = ra * VG_BK + ((gq ^ ((ra >> 2) & 2)) * 8);
+    offb[i] = 128 * VG_BK + rb * VG_BK + ((gq ^ ((rb >> 2) & 2)) * 8);
+  }
+  auto load_frags = [&](int kt, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+    const bf16_t* ls = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wn * 64 + j * 16 + l16;
-      fb[j] = *reinterpret_cast<const bf16x8*>(lb + r * VG_BK + ((gq ^ ((r >> 2) & 2)) * 8));
-    }
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ls + offa[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(ls + offb[j]);
+  };
+  auto mfmas = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) Mma<MODE_BF16>::mma(acc[i][j], fa[i], fb[j]);
+  };
+  // One pipeline step for K-tile kt whose fragments are already in (ca, cb):
+  //   issue the DMA of tile kt+4 (its slot held tile kt-1, whose fragment reads finished an iteration ago),
+  //   issue the LDS reads of tile kt+1 into (na, nb), run the 16 MFMAs of tile kt underneath them, then make
+  //   tile kt+2 visible: counted vmcnt (tiles kt+3, kt+4 stay in flight) + one barrier.
+  auto step = [&](int kt, const bf16x8 (&ca)[4], const bf16x8 (&cb)[4], bf16x8 (&na)[4], bf16x8 (&nb)[4]) {
+    if (kt + 4 < nk) stage(kt + 4);
+    if (kt + 1 < nk) load_frags(kt + 1, na, nb);
+    mfmas(ca, cb);
+    const int ahead = nk - 1 - (kt + 2);   // tiles issued beyond kt+2
+    // The fragment reads of tile kt+1 had the whole MFMA block to land: retire them here, so that the next step's
+    // MFMAs start without an lgkmcnt(0) that would also wait for the reads issued just in front of them.
+    // (an empty asm that "uses" the fragment registers: hipcc places its own lgkmcnt wait for them HERE, behind the
+    //  MFMAs, and treats them as plain registers afterwards)
+    __builtin_amdgcn_sched_barrier(0);   // keep the 16 MFMAs in front of the wait the next line provokes
+    asm volatile("" : "+v"(na[0]), "+v"(na[1]), "+v"(na[2]), "+v"(na[3]), "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]));
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  stage(0);
+  stage(1);
+  stage(2);
+  stage(3);
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tiles 0 and 1 landed (this wave's part)
+  __builtin_amdgcn_s_barrier();
+  load_frags(0, fa0, fb0);
+  asm volatile("" : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]));
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, fa0, fb0, fa1, fb1);
+    step(kt + 1, fa1, fb1, fa0, fb0);
   }
+  if (kt < nk) step(kt, fa0, fb0, fa1, fb1);
   __syncthreads();  // all waves done reading the ring before the epilogue reuses it
 
   if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
@@ -202,7 +231,7 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
                                void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
                                void* stream) {
   MAAVSS_CHECK_ARG(A && W && C && M > 0, "vit_gemm: bad arguments");
-  MAAVSS_CHECK_ARG(N % 128 == 0 && K % VG_BK == 0 && K >= 3 * VG_BK, "vit_gemm: N must be a multiple of 128 and K of 32, K >= 96 (N=%d K=%d)", N, K);
+  MAAVSS_CHECK_ARG(N % 128 == 0 && K % VG_BK == 0 && K >= 4 * VG_BK, "vit_gemm: N must be a multiple of 128 and K of 32, K >= 128 (N=%d K=%d)", N, K);
   MAAVSS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0, "vit_gemm: leading dimensions must be multiples of 8");
   MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "vit_gemm: unknown epilogue");
   MAAVSS_CHECK_ARG(epilogue == EPI_F32_ROWTABLE ? (table && period > 0) : (bias != nullptr), "vit_gemm: missing bias/table");
@@ -213,7 +242,15 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   g.qscale_cols = qscale_cols; g.qscale = qscale;
   g.tiles_n = N / 128; g.tiles_m = cdiv(M, 128);
   const dim3 grid(g.tiles_n * g.tiles_m), block(256);
-  const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 64 KiB
+  const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 80 KiB: two workgroups fill a CU's 160 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_BF16_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_BF16_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_F32_BIAS_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_F32_ROWTABLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case EPI_BF16_BIAS: hipLaunchKernelGGL(vit_gemm_kernel<EPI_BF16_BIAS>, grid, block, smem, st, g); break;
