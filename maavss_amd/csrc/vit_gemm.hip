@@ -5,17 +5,19 @@
 //
 //   C[M,N] = epilogue( A[M,K] (bf16, row-major) . W[N,K]^T (bf16, torch Linear layout) )
 //
-// 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles), BK = 32.
-// These GEMMs have SHORT K (384 / 1536 / 192), so the cost is latency per tile, not steady-state issue:
-//   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 5-slot ring; up to three
-//     K-steps stay in flight across a raw s_barrier behind a counted s_waitcnt vmcnt (never 0 in the loop);
-//   * the LDS fragment reads of K-step kt+1 are issued BEFORE the 16 MFMAs of K-step kt (two named fragment
-//     sets, loop unrolled by two), so LDS latency hides under the matrix pipe instead of in front of it;
-//   * 80 KiB of LDS per workgroup -> two workgroups per CU overlap each other's prologue / epilogue;
-//   * the LDS image is lane-linear, so the bank swizzle (16-B chunk ^= (row>>2)&2, conflict-free for the
-//     ds_read_b128 lane groups on 64-B rows) is applied to the per-lane SOURCE address and again on the read;
+// 256x128 output tile per 512-thread workgroup (4x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles), BK = 64.
+// These GEMMs have SHORT K (384 / 1536 / 192): what limits them is the L2 -> LDS feed, not MFMA issue
+// (measured: a 128x128 / BK=32 version spent 88 % of its time with the MFMAs removed, because every 128-B line
+// was requested twice as two 64-B halves).  Hence:
+//   * BK = 64 bf16 = one full 128-B line per row and staging instruction; 256x128 tile = 85 FLOP per staged byte;
+//   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 3-slot ring (144 KiB, one
+//     workgroup of 8 waves per CU); two K-steps stay in flight across a raw s_barrier behind a counted vmcnt;
+//   * the LDS fragment reads of the next 32-deep sub-step are issued BEFORE the 16 MFMAs of the current one (two
+//     named fragment sets), so LDS latency hides under the matrix pipe;
+//   * the LDS image is lane-linear, so the bank swizzle (16-B chunk ^= row & 7) is applied to the per-lane SOURCE
+//     address and again on the ds_read_b128 side;
 //   * blocks are remapped so that the N-tiles of one M-panel run on the same XCD (A panel from that L2).
-// Epilogues: +bias (and 1/8 on the q third) -> bf16 | +bias, GELU -> bf16 | +bias +residual -> f32 (in place
+// Epilogues: +bias (and log2e/8 on the q third) -> bf16 | +bias, GELU -> bf16 | +bias +residual -> f32 (in place
 // on the residual stream) | + periodic row table (conv bias / cls token + position embedding) -> f32.
 // All outputs are staged through LDS and written as full rows (16 B per lane).
 #include "mma.h"
@@ -25,9 +27,13 @@
 #define EPI_F32_BIAS_RESID 2
 #define EPI_F32_ROWTABLE 3
 
-#define VG_BK 32
-#define VG_STAGES 5
-#define VG_STAGE_ELEMS (2 * 128 * VG_BK)  // A tile + B tile, bf16 elements
+#define VG_BM 256
+#define VG_BN 128
+#define VG_BK 64
+#define VG_STAGES 3
+#define VG_THREADS 512
+#define VG_STAGE_ELEMS ((VG_BM + VG_BN) * VG_BK)  // A tile + B tile, bf16 elements (48 KiB)
+#define VG_LOADS 6                                 // global_load_lds per wave per stage (4 A + 2 B)
 
 struct VGemmArgs {
   const bf16_t* A;
@@ -58,9 +64,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
+__global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [4 stages][A 128x32 | B 128x32] bf16 = 64 KiB
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [3 stages][A 256x64 | B 128x64] bf16 = 144 KiB
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int nwg = g.tiles_m * g.tiles_n;
@@ -70,29 +76,31 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 128;
+  const int m0 = tm * VG_BM, n0 = tn * VG_BN;
 
-  // staging: one wave-instruction = 16 rows x 64 B; wave wv stages rows [wv*32, wv*32+32) of A and of B.
-  const int srow = lane >> 2, sslot = lane & 3;
-  const bf16_t* asrc[2];
+  // staging: one wave-instruction = 8 rows x 128 B.  Wave wv stages A rows [wv*32, +32) and B rows [wv*16, +16).
+  const int srow = lane >> 3, sslot = lane & 7;
+  const bf16_t* asrc[4];
   const bf16_t* bsrc[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wv * 32 + i * 16 + srow;
-    const int gc = sslot ^ ((r >> 2) & 2);
+  for (int i = 0; i < 4; ++i) {
+    const int r = wv * 32 + i * 8 + srow;
     int ar = m0 + r;
     ar = ar < g.M ? ar : g.M - 1;
-    asrc[i] = g.A + (int64_t)ar * g.lda + gc * 8;
-    bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + gc * 8;
+    asrc[i] = g.A + (int64_t)ar * g.lda + ((sslot ^ (r & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wv * 16 + i * 8 + srow;
+    bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + ((sslot ^ (r & 7)) * 8);
   }
   auto stage = [&](int kt) {
     bf16_t* la = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
-    bf16_t* lb = la + 128 * VG_BK;
+    bf16_t* lb = la + VG_BM * VG_BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(asrc[i] + kt * VG_BK, la + (wv * 32 + i * 16) * VG_BK + lane * 8);
-      glds16(bsrc[i] + kt * VG_BK, lb + (wv * 32 + i * 16) * VG_BK + lane * 8);
-    }
+    for (int i = 0; i < 4; ++i) glds16(asrc[i] + kt * VG_BK, la + (wv * 32 + i * 8) * VG_BK + lane * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(bsrc[i] + kt * VG_BK, lb + (wv * 16 + i * 8) * VG_BK + lane * 8);
   };
 
   f32x4 acc[4][4];
@@ -101,22 +109,22 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / VG_BK;  // >= 4 (checked by the launcher)
+  const int nk = g.K / VG_BK;  // >= 2 (checked by the launcher)
   const int l16 = lane & 15, gq = lane >> 4;
-  // per-lane fragment offsets inside a stage (swizzled), constant over the K loop
-  int offa[4], offb[4];
+  int rowa[4], rowb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + l16, rb = wn * 64 + i * 16 + l16;
-    offa[i] = ra * VG_BK + ((gq ^ ((ra >> 2) & 2)) * 8);
-    offb[i] = 128 * VG_BK + rb * VG_BK + ((gq ^ ((rb >> 2) & 2)) * 8);
+    rowa[i] = wm * 64 + i * 16 + l16;
+    rowb[i] = wn * 64 + i * 16 + l16;
   }
-  auto load_frags = [&](int kt, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
-    const bf16_t* ls = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
+  // fragments of sub-step s (k = 32 s .. 32 s + 31) of the K tile in ring slot `slot`
+  auto load_frags = [&](int slot, int s, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+    const bf16_t* la = lds + slot * VG_STAGE_ELEMS;
+    const bf16_t* lb = la + VG_BM * VG_BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ls + offa[i]);
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(la + rowa[i] * VG_BK + (((s * 4 + gq) ^ (rowa[i] & 7)) * 8));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(ls + offb[j]);
+    for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rowb[j] * VG_BK + (((s * 4 + gq) ^ (rowb[j] & 7)) * 8));
   };
   auto mfmas = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
 #pragma unroll
@@ -124,46 +132,41 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) Mma<MODE_BF16>::mma(acc[i][j], fa[i], fb[j]);
   };
-  // One pipeline step for K-tile kt whose fragments are already in (ca, cb):
-  //   issue the DMA of tile kt+4 (its slot held tile kt-1, whose fragment reads finished an iteration ago),
-  //   issue the LDS reads of tile kt+1 into (na, nb), run the 16 MFMAs of tile kt underneath them, then make
-  //   tile kt+2 visible: counted vmcnt (tiles kt+3, kt+4 stay in flight) + one barrier.
-  auto step = [&](int kt, const bf16x8 (&ca)[4], const bf16x8 (&cb)[4], bf16x8 (&na)[4], bf16x8 (&nb)[4]) {
-    if (kt + 4 < nk) stage(kt + 4);
-    if (kt + 1 < nk) load_frags(kt + 1, na, nb);
-    mfmas(ca, cb);
-    const int ahead = nk - 1 - (kt + 2);   // tiles issued beyond kt+2
-    // The fragment reads of tile kt+1 had the whole MFMA block to land: retire them here, so that the next step's
-    // MFMAs start without an lgkmcnt(0) that would also wait for the reads issued just in front of them.
-    // (an empty asm that "uses" the fragment registers: hipcc places its own lgkmcnt wait for them HERE, behind the
-    //  MFMAs, and treats them as plain registers afterwards)
-    __builtin_amdgcn_sched_barrier(0);   // keep the 16 MFMAs in front of the wait the next line provokes
-    asm volatile("" : "+v"(na[0]), "+v"(na[1]), "+v"(na[2]), "+v"(na[3]), "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]));
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
+#define VG_USE_FRAGS(fa, fb)                 \
+  __builtin_amdgcn_sched_barrier(0);         \
+  asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]))
+
   stage(0);
-  stage(1);
-  stage(2);
-  stage(3);
+  if (nk > 1) stage(1);
   bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tiles 0 and 1 landed (this wave's part)
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed (this wave's part)
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  load_frags(0, fa0, fb0);
-  asm volatile("" : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]));
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    step(kt, fa0, fb0, fa1, fb1);
-    step(kt + 1, fa1, fb1, fa0, fb0);
+  load_frags(0, 0, fa0, fb0);
+  VG_USE_FRAGS(fa0, fb0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int slot = kt % VG_STAGES;
+    // the slot of tile kt-1 is free: every wave finished its fragment reads before the last barrier
+    if (kt + 2 < nk) stage(kt + 2);
+    // sub-step 0: reads of sub-step 1 go out first, the 16 MFMAs of sub-step 0 run underneath them
+    load_frags(slot, 1, fa1, fb1);
+    mfmas(fa0, fb0);
+    VG_USE_FRAGS(fa1, fb1);   // hipcc places its lgkmcnt wait here, behind the MFMAs
+    // make tile kt+1 visible before its first fragments are read: counted vmcnt (tile kt+2 stays in flight) + barrier
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      load_frags((kt + 1) % VG_STAGES, 0, fa0, fb0);
+    }
+    mfmas(fa1, fb1);          // sub-step 1 under the reads of the next tile's sub-step 0
+    if (kt + 1 < nk) { VG_USE_FRAGS(fa0, fb0); }
   }
-  if (kt < nk) step(kt, fa0, fb0, fa1, fb1);
-  __syncthreads();  // all waves done reading the ring before the epilogue reuses it
+  __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
   if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
     constexpr int LDC = 136;  // bf16 elements per staged row (272 B)
-    bf16_t* cs = lds;
+    bf16_t* cs = lds;         // [256][136] bf16 = 68 KiB
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int nl = wn * 64 + j * 16 + l16;
@@ -184,20 +187,20 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
     bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int q = it * 256 + tid, row = q >> 4, c16 = q & 15;
+      const int q = it * VG_THREADS + tid, row = q >> 4, c16 = q & 15;
       if (m0 + row < g.M)
         *reinterpret_cast<uint4*>(C + (int64_t)(m0 + row) * g.ldc + n0 + c16 * 8) =
             *reinterpret_cast<const uint4*>(cs + row * LDC + c16 * 8);
     }
   } else {
-    // f32 outputs: two passes of 64 rows through a [64][132] f32 LDS image, then float4 read-modify-write rows
+    // f32 outputs: four passes of 64 rows through a [64][132] f32 LDS image, then float4 read-modify-write rows
     constexpr int LDF = 132;
     float* cf = reinterpret_cast<float*>(smem);
     float* C = reinterpret_cast<float*>(g.C);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (half) __syncthreads();
-      if (wm == half) {
+    for (int pass = 0; pass < 4; ++pass) {
+      if (pass) __syncthreads();
+      if (wm == pass) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -207,9 +210,9 @@ __global__ __launch_bounds__(256, 2) void vit_gemm_kernel(VGemmArgs g) {
       }
       __syncthreads();
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int q = it * 256 + tid, row = q >> 5, c4 = (q & 31) * 4;
-        const int m = m0 + half * 64 + row;
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * VG_THREADS + tid, row = q >> 5, c4 = (q & 31) * 4;
+        const int m = m0 + pass * 64 + row;
         if (m < g.M) {
           const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
           float4* cp = reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n0 + c4);
@@ -231,7 +234,7 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
                                void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
                                void* stream) {
   MAAVSS_CHECK_ARG(A && W && C && M > 0, "vit_gemm: bad arguments");
-  MAAVSS_CHECK_ARG(N % 128 == 0 && K % VG_BK == 0 && K >= 4 * VG_BK, "vit_gemm: N must be a multiple of 128 and K of 32, K >= 128 (N=%d K=%d)", N, K);
+  MAAVSS_CHECK_ARG(N % VG_BN == 0 && K % VG_BK == 0 && K >= VG_BK, "vit_gemm: N must be a multiple of 128 and K of 64 (N=%d K=%d)", N, K);
   MAAVSS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0, "vit_gemm: leading dimensions must be multiples of 8");
   MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "vit_gemm: unknown epilogue");
   MAAVSS_CHECK_ARG(epilogue == EPI_F32_ROWTABLE ? (table && period > 0) : (bias != nullptr), "vit_gemm: missing bias/table");
@@ -240,9 +243,9 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.table = table; g.C = C;
   g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.period = period;
   g.qscale_cols = qscale_cols; g.qscale = qscale;
-  g.tiles_n = N / 128; g.tiles_m = cdiv(M, 128);
-  const dim3 grid(g.tiles_n * g.tiles_m), block(256);
-  const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 80 KiB: two workgroups fill a CU's 160 KiB
+  g.tiles_n = N / VG_BN; g.tiles_m = cdiv(M, VG_BM);
+  const dim3 grid(g.tiles_n * g.tiles_m), block(VG_THREADS);
+  const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 144 KiB
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_BF16_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
