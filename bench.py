@@ -137,10 +137,18 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE (launch with torch.distributed.run)",
               file=sys.stderr)
+    # Rehearsal knobs for a box with fewer GPUs than ranks (never used by the driver): all ranks on device 0
+    # and/or the gloo backend.  The collective code path (trainer.GradSync) is the same.
+    if os.environ.get("MAAVSS_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MAAVSS_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import maavss_amd
     from maavss_amd import _lib
