@@ -103,11 +103,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
     for (int ch = 0; ch < NCHUNK; ++ch) {
       constexpr int WV = (COUT * NCW + 255) / 256;
       uint4 wreg[WV];
-      if (ch + 1 < NCHUNK) {
+      {
+        // unconditional (clamped) loads keep wreg in registers: a conditionally written array lands in scratch
+        const int chn = ch + 1 < NCHUNK ? ch + 1 : ch;
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
-          const int i = v * 256 + tid;
-          if (i < COUT * NCW) wreg[v] = *reinterpret_cast<const uint4*>(wk + (int64_t)(i / NCW) * KP + (ch + 1) * 64 + (i % NCW) * EPC);
+          int i = v * 256 + tid;
+          i = i < COUT * NCW ? i : 0;
+          wreg[v] = *reinterpret_cast<const uint4*>(wk + (int64_t)(i / NCW) * KP + chn * 64 + (i % NCW) * EPC);
         }
       }
       const E* wb = wl + (ch & 1) * COUT * 64;

@@ -21,6 +21,7 @@
 #define ATT_D 64
 #define ATT_QT 128
 #define ATT_KT 64
+#define ATT_THR 5.0f  // log2 units: rescale only when the running maximum grows by more than 2^5
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
+  float mrow[2] = {0.f, 0.f}, lrow[2] = {0.f, 0.f};   // the first tile rebases m_run unconditionally
 
   // staging map: thread -> (key = idx>>3, 16-B chunk c = idx&7) for idx = tid and tid + 256
   uint4 kreg[2], vreg[2];
@@ -92,11 +93,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
     const int buf = kt & 1, kv0 = kt * ATT_KT;
     if (kt + 1 < ntiles) load_tile(kv0 + ATT_KT);
     // ---- S^T = K Q^T : s[t][nt][r] = score(key 16 nt + 4 gq + r, query t*16 + l16)
+    // The running row maximum goes in as the MFMA's C operand (s' = score - m_run), so no subtraction pass.
     f32x4 s[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      s[0][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s[1][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[0][nt] = f32x4{-mrow[0], -mrow[0], -mrow[0], -mrow[0]};
+      s[1][nt] = f32x4{-mrow[1], -mrow[1], -mrow[1], -mrow[1]};
       const int key = nt * 16 + l16;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -113,33 +115,50 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
           if (kv0 + nt * 16 + gq * 4 + r >= ntok) { s[0][nt][r] = -1e30f; s[1][nt][r] = -1e30f; }
     }
     // ---- online softmax (base 2), query on the lane
+    // Deferred rescale: m_run only moves when the tile maximum exceeds it by more than ATT_THR (then P <= 2^ATT_THR,
+    // harmless in f32 / bf16); the O / l rescale is a rare wave-uniform branch instead of 32 multiplies per tile.
     bf16x8 fp[2][2];
+    float mx[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float mx = s[t][0][0];
+      float m01 = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+      float m23 = fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3]));
+      float m45 = fmaxf(fmaxf(s[t][2][0], s[t][2][1]), fmaxf(s[t][2][2], s[t][2][3]));
+      float m67 = fmaxf(fmaxf(s[t][3][0], s[t][3][1]), fmaxf(s[t][3][2], s[t][3][3]));
+      float m = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      mx[t] = fmaxf(m, __shfl_xor(m, 32, 64));
+    }
+    const bool first = kt == 0;
+    if (__any(first || mx[0] > ATT_THR || mx[1] > ATT_THR)) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int t = 0; t < 2; ++t) {
+        const float delta = (first || mx[t] > ATT_THR) ? mx[t] : 0.f;   // first tile: rebase in either direction
+        const float alpha = fast_exp2(-delta);
+        mrow[t] += delta;
+        lrow[t] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][nt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(mrow[t], mx);
-      const float alpha = fast_exp2(mrow[t] - mn);
-      mrow[t] = mn;
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][nt][r] -= delta;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
       float sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[t][nt][r] - mn);
+          const float p = fast_exp2(s[t][nt][r]);
           s[t][nt][r] = p;
           sum += p;
         }
-      lrow[t] = lrow[t] * alpha + sum;  // per-lane partial; the 4 lanes of a query are summed at the end
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+      lrow[t] += sum;  // per-lane partial; the 4 lanes of a query are summed at the end
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const unsigned w0 = pack_bf2(s[t][2 * ks][0], s[t][2 * ks][1]), w1 = pack_bf2(s[t][2 * ks][2], s[t][2 * ks][3]);
