@@ -45,6 +45,14 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
+// Two 4 x 16-bit halves (e.g. two ds_read_b64_tr_b16 results) -> one 8 x 16-bit MFMA fragment, as a pure
+// register-pair concatenation (an element-wise vector initialiser makes hipcc emit per-element pack code).
+__device__ __forceinline__ bf16x8 concat4(bf16x4 lo, bf16x4 hi) {
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  const uint4 u = make_uint4(a.x, a.y, b.x, b.y);
+  return __builtin_bit_cast(bf16x8, u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

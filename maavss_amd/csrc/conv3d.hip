@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             const E* a = ds + ((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + (l16 & 3) * 4;
             h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
           }
-          fb[j] = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+          fb[j] = concat4(h[0], h[1]);
         }
       }
 #pragma unroll
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
               const E* a = xs + ((2 * ks + (k >> 4)) * 20 + (k & 15) + kw) * CI + mi * 16 + (l16 & 3) * 4;
               h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
             }
-            fa = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+            fa = concat4(h[0], h[1]);
           }
 #pragma unroll
           for (int j = 0; j < NT; ++j) M::mma(acc[p][j], fa, fb[j]);

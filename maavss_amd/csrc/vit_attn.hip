@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
           const bf16_t* a = &Vs[buf][key * ATT_D + ((dt ^ ((key >> 1) & 3)) * 16) + (l16 & 3) * 4];
           h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
         }
-        const bf16x8 fv = bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+        const bf16x8 fv = concat4(h[0], h[1]);
         Mma<MODE_BF16>::mma(o[0][dt], fv, fp[0][ks]);
         Mma<MODE_BF16>::mma(o[1][dt], fv, fp[1][ks]);
       }
