@@ -12,6 +12,9 @@
 //   * BK = 64 bf16 = one full 128-B line per row and staging instruction; 256x128 tile = 85 FLOP per staged byte;
 //   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 3-slot ring (144 KiB, one
 //     workgroup of 8 waves per CU); two K-steps stay in flight across a raw s_barrier behind a counted vmcnt;
+//   * the workgroups are PERSISTENT (one per CU) and the DMA stream runs across tile boundaries: while a tile's
+//     epilogue runs (staged through the ring slot that just became free), the first two K-steps of the next
+//     tile are already in flight, so the per-tile prologue latency -- the dominant cost at K = 384 -- is hidden;
 //   * the LDS fragment reads of the next 32-deep sub-step are issued BEFORE the 16 MFMAs of the current one (two
 //     named fragment sets), so LDS latency hides under the matrix pipe;
 //   * the LDS image is lane-linear, so the bank swizzle (16-B chunk ^= row & 7) is applied to the per-lane SOURCE
@@ -66,36 +69,49 @@ __device__ __forceinline__ float gelu_erf(float v) {
 template <int EPI>
 __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [3 stages][A 256x64 | B 128x64] bf16 = 144 KiB
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [3 slots][A 256x64 | B 128x64] bf16 = 144 KiB
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
-  const int nwg = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-  const int m0 = tm * VG_BM, n0 = tn * VG_BN;
+  const int l16 = lane & 15, gq = lane >> 4;
+  const int nk = g.K / VG_BK;
 
-  // staging: one wave-instruction = 8 rows x 128 B.  Wave wv stages A rows [wv*32, +32) and B rows [wv*16, +16).
+  // ---- persistent tile schedule.  Blocks are dealt round-robin over the 8 XCDs; XCD x owns a contiguous range
+  // of tiles (tn fastest), its blocks take them round-robin, so co-running blocks of one XCD share A panels in L2.
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q8 = ntiles / 8, r8 = ntiles % 8;
+  const int lo = xcd * q8 + min(xcd, r8), hi = lo + q8 + (xcd < r8 ? 1 : 0);
+  const int my_first = lo + lane_in_xcd;
+  const int my_count = my_first < hi ? (hi - my_first + per_xcd - 1) / per_xcd : 0;
+  if (my_count == 0) return;
+  const int total_steps = my_count * nk;  // virtual K-step stream across this block's tiles
+
+  // ---- staging stream state (runs two K-steps ahead of the MFMAs, across tile boundaries)
   const int srow = lane >> 3, sslot = lane & 7;
   const bf16_t* asrc[4];
   const bf16_t* bsrc[2];
+  int s_tile = -1;
+  auto set_stage_tile = [&](int ti) {
+    const int id = my_first + ti * per_xcd;
+    const int m0 = (id / g.tiles_n) * VG_BM, n0 = (id % g.tiles_n) * VG_BN;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wv * 32 + i * 8 + srow;
-    int ar = m0 + r;
-    ar = ar < g.M ? ar : g.M - 1;
-    asrc[i] = g.A + (int64_t)ar * g.lda + ((sslot ^ (r & 7)) * 8);
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int r = wv * 32 + i * 8 + srow;
+      int ar = m0 + r;
+      ar = ar < g.M ? ar : g.M - 1;
+      asrc[i] = g.A + (int64_t)ar * g.lda + ((sslot ^ (r & 7)) * 8);
+    }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wv * 16 + i * 8 + srow;
-    bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + ((sslot ^ (r & 7)) * 8);
-  }
-  auto stage = [&](int kt) {
-    bf16_t* la = lds + (kt % VG_STAGES) * VG_STAGE_ELEMS;
+    for (int i = 0; i < 2; ++i) {
+      const int r = wv * 16 + i * 8 + srow;
+      bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + ((sslot ^ (r & 7)) * 8);
+    }
+    s_tile = ti;
+  };
+  auto stage = [&](int v) {  // virtual step v -> ring slot v % 3
+    const int ti = v / nk, kt = v - ti * nk;
+    if (ti != s_tile) set_stage_tile(ti);
+    bf16_t* la = lds + (v % VG_STAGES) * VG_STAGE_ELEMS;
     bf16_t* lb = la + VG_BM * VG_BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(asrc[i] + kt * VG_BK, la + (wv * 32 + i * 8) * VG_BK + lane * 8);
@@ -103,21 +119,12 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
     for (int i = 0; i < 2; ++i) glds16(bsrc[i] + kt * VG_BK, lb + (wv * 16 + i * 8) * VG_BK + lane * 8);
   };
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / VG_BK;  // >= 2 (checked by the launcher)
-  const int l16 = lane & 15, gq = lane >> 4;
   int rowa[4], rowb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     rowa[i] = wm * 64 + i * 16 + l16;
     rowb[i] = wn * 64 + i * 16 + l16;
   }
-  // fragments of sub-step s (k = 32 s .. 32 s + 31) of the K tile in ring slot `slot`
   auto load_frags = [&](int slot, int s, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
     const bf16_t* la = lds + slot * VG_STAGE_ELEMS;
     const bf16_t* lb = la + VG_BM * VG_BK;
@@ -126,6 +133,7 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rowb[j] * VG_BK + (((s * 4 + gq) ^ (rowb[j] & 7)) * 8));
   };
+  f32x4 acc[4][4];
   auto mfmas = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -137,95 +145,120 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
   asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]))
 
   stage(0);
-  if (nk > 1) stage(1);
+  if (total_steps > 1) stage(1);
   bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed (this wave's part)
+  if (total_steps > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step 0 landed (this wave's part)
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   load_frags(0, 0, fa0, fb0);
   VG_USE_FRAGS(fa0, fb0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int slot = kt % VG_STAGES;
-    // the slot of tile kt-1 is free: every wave finished its fragment reads before the last barrier
-    if (kt + 2 < nk) stage(kt + 2);
-    // sub-step 0: reads of sub-step 1 go out first, the 16 MFMAs of sub-step 0 run underneath them
-    load_frags(slot, 1, fa1, fb1);
-    mfmas(fa0, fb0);
-    VG_USE_FRAGS(fa1, fb1);   // hipcc places its lgkmcnt wait here, behind the MFMAs
-    // make tile kt+1 visible before its first fragments are read: counted vmcnt (tile kt+2 stays in flight) + barrier
-    if (kt + 1 < nk) {
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      load_frags((kt + 1) % VG_STAGES, 0, fa0, fb0);
-    }
-    mfmas(fa1, fb1);          // sub-step 1 under the reads of the next tile's sub-step 0
-    if (kt + 1 < nk) { VG_USE_FRAGS(fa0, fb0); }
-  }
-  __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
-  if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
-    constexpr int LDC = 136;  // bf16 elements per staged row (272 B)
-    bf16_t* cs = lds;         // [256][136] bf16 = 68 KiB
+  int v = 0;
+  for (int ti = 0; ti < my_count; ++ti) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nl = wn * 64 + j * 16 + l16;
-      const int n = n0 + nl;
-      const float bv = g.bias[n];
-      const float sc = (EPI == EPI_BF16_BIAS && n < g.qscale_cols) ? g.qscale : 1.f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv;
-          if constexpr (EPI == EPI_BF16_BIAS_GELU) v = gelu_erf(v);
-          else v *= sc;
-          cs[(wm * 64 + i * 16 + gq * 4 + r) * LDC + nl] = f2bf(v);
-        }
-    }
-    __syncthreads();
-    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int q = it * VG_THREADS + tid, row = q >> 4, c16 = q & 15;
-      if (m0 + row < g.M)
-        *reinterpret_cast<uint4*>(C + (int64_t)(m0 + row) * g.ldc + n0 + c16 * 8) =
-            *reinterpret_cast<const uint4*>(cs + row * LDC + c16 * 8);
-    }
-  } else {
-    // f32 outputs: four passes of 64 rows through a [64][132] f32 LDS image, then float4 read-modify-write rows
-    constexpr int LDF = 132;
-    float* cf = reinterpret_cast<float*>(smem);
-    float* C = reinterpret_cast<float*>(g.C);
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      if (pass) __syncthreads();
-      if (wm == pass) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cf[(i * 16 + gq * 4 + r) * LDF + wn * 64 + j * 16 + l16] = acc[i][j][r];
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt, ++v) {
+      const int slot = v % VG_STAGES;
+      // slot of step v-1 is free (all fragment reads of step v-1 retired before the last barrier) -> refill it
+      const bool issued = v + 2 < total_steps;
+      if (issued) stage(v + 2);
+      load_frags(slot, 1, fa1, fb1);   // sub-step 1 reads go out first, sub-step 0 MFMAs run underneath
+      mfmas(fa0, fb0);
+      VG_USE_FRAGS(fa1, fb1);
+      if (kt + 1 < nk) {
+        // make step v+1 visible: counted vmcnt (the step issued above may stay in flight) + barrier
+        if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags((v + 1) % VG_STAGES, 0, fa0, fb0);
       }
-      __syncthreads();
+      mfmas(fa1, fb1);
+      if (kt + 1 < nk) { VG_USE_FRAGS(fa0, fb0); }
+    }
+    // ---- tile done.  Steps v, v+1 (next tile) are already in flight in the other two slots; the slot of the last
+    // step (v-1) is free and serves as the epilogue staging buffer, so the next tile's prologue latency hides here.
+    __builtin_amdgcn_s_barrier();   // every wave has finished its fragment reads of the last step
+    {
+      const int id = my_first + ti * per_xcd;
+      const int m0 = (id / g.tiles_n) * VG_BM, n0 = (id % g.tiles_n) * VG_BN;
+      char* ebuf = smem + ((v - 1) % VG_STAGES) * (VG_STAGE_ELEMS * 2);
+      if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
+        constexpr int LDC = 136;  // [128][136] bf16 = 34 KiB per pass
+        bf16_t* cs = reinterpret_cast<bf16_t*>(ebuf);
+        bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int q = it * VG_THREADS + tid, row = q >> 5, c4 = (q & 31) * 4;
-        const int m = m0 + pass * 64 + row;
-        if (m < g.M) {
-          const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
-          float4* cp = reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n0 + c4);
-          float4 add;
-          if constexpr (EPI == EPI_F32_BIAS_RESID) {
-            const float4 res = *cp, bb = *reinterpret_cast<const float4*>(g.bias + n0 + c4);
-            add = make_float4(res.x + bb.x, res.y + bb.y, res.z + bb.z, res.w + bb.w);
-          } else {
-            add = *reinterpret_cast<const float4*>(g.table + (int64_t)(m % g.period) * g.N + n0 + c4);
+        for (int pass = 0; pass < 2; ++pass) {
+          if (pass) __syncthreads();
+          if ((wm >> 1) == pass) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nl = wn * 64 + j * 16 + l16;
+              const int n = n0 + nl;
+              const float bv = g.bias[n];
+              const float sc = (EPI == EPI_BF16_BIAS && n < g.qscale_cols) ? g.qscale : 1.f;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float val = acc[i][j][r] + bv;
+                  if constexpr (EPI == EPI_BF16_BIAS_GELU) val = gelu_erf(val);
+                  else val *= sc;
+                  cs[((wm & 1) * 64 + i * 16 + gq * 4 + r) * LDC + nl] = f2bf(val);
+                }
+            }
           }
-          *cp = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int q = it * VG_THREADS + tid, row = q >> 4, c16 = q & 15;
+            const int m = m0 + pass * 128 + row;
+            if (m < g.M)
+              *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n0 + c16 * 8) = *reinterpret_cast<const uint4*>(cs + row * LDC + c16 * 8);
+          }
+        }
+      } else {
+        constexpr int LDF = 132;  // [64][132] f32 = 33 KiB per pass
+        float* cf = reinterpret_cast<float*>(ebuf);
+        float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          if (pass) __syncthreads();
+          if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cf[(i * 16 + gq * 4 + r) * LDF + wn * 64 + j * 16 + l16] = acc[i][j][r];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int q = it * VG_THREADS + tid, row = q >> 5, c4 = (q & 31) * 4;
+            const int m = m0 + pass * 64 + row;
+            if (m < g.M) {
+              const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
+              float4* cp = reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n0 + c4);
+              float4 add;
+              if constexpr (EPI == EPI_F32_BIAS_RESID) {
+                const float4 res = *cp, bb = *reinterpret_cast<const float4*>(g.bias + n0 + c4);
+                add = make_float4(res.x + bb.x, res.y + bb.y, res.z + bb.z, res.w + bb.w);
+              } else {
+                add = *reinterpret_cast<const float4*>(g.table + (int64_t)(m % g.period) * g.N + n0 + c4);
+              }
+              *cp = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
+            }
+          }
         }
       }
+    }
+    if (ti + 1 < my_count) {
+      // everything issued so far (the next tile's first two steps and this tile's stores) has landed / drained
+      __syncthreads();   // = s_waitcnt vmcnt(0) lgkmcnt(0) + barrier: the staging slot is free again, step v is visible
+      load_frags(v % VG_STAGES, 0, fa0, fb0);
+      VG_USE_FRAGS(fa0, fb0);
     }
   }
 }
@@ -244,7 +277,10 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.period = period;
   g.qscale_cols = qscale_cols; g.qscale = qscale;
   g.tiles_n = N / VG_BN; g.tiles_m = cdiv(M, VG_BM);
-  const dim3 grid(g.tiles_n * g.tiles_m), block(VG_THREADS);
+  // persistent: one workgroup per CU (144 KiB LDS each), a multiple of 8 so every XCD gets the same number
+  int nblocks = g.tiles_n * g.tiles_m;
+  nblocks = nblocks >= 256 ? 256 : cdiv(nblocks, 8) * 8;
+  const dim3 grid(nblocks), block(VG_THREADS);
   const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 144 KiB
   static bool attr_set = false;
   if (!attr_set) {
