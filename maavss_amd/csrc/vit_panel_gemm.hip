@@ -1,0 +1,262 @@
+// K2+K3 fused: the K = 384 dense layers of the ViT blocks (qkv, proj, mlp.fc1) with the preceding LayerNorm folded
+// into the GEMM -- dino Block: norm1 -> attn.qkv, attn.proj, norm2 -> mlp.fc1 (reached from the reference through
+// video_attention.py:52).  Why a second GEMM kernel: at K = 384 the tiled kernel (vit_gemm.hip) is bound by the
+// L2 -> LDS feed (48 KiB of operands per 256x128x64 step) and by epilogues that nothing overlaps.  Here the
+// activation panel is STATIONARY:
+//   * a workgroup (8 waves) owns 128 rows; the whole [128 x 384] bf16 panel lives in LDS (96 KiB) and is built once
+//     -- either by LayerNorm-ing the f32 residual rows on the way in (one wave per row, wave reductions; the
+//     normalised tensor never exists in HBM and the LayerNorm kernel disappears), or by DMA for a bf16 input;
+//   * only the weights stream: [128 n x 64 k] tiles (16 KiB, L2-resident) through a 3-slot global_load_lds ring
+//     that runs continuously over all N tiles of the panel -- a third of the staged bytes per FLOP;
+//   * the MFMA roles are swapped (weights = A operand, activations = B operand), so an accumulator lane holds
+//     4 CONSECUTIVE output columns of one row: the epilogue stores 8 B (bf16) / 16 B (f32 read-modify-write)
+//     straight from registers -- no LDS staging, no barrier, and other waves' MFMAs keep running underneath.
+// Epilogues: 0 +bias, q-scale -> bf16 | 1 +bias, GELU -> bf16 | 2 +bias +residual -> f32 in place.
+#include "mma.h"
+
+#define PG_K 384
+#define PG_BM 128
+#define PG_BN 128
+#define PG_BK 64
+#define PG_STAGES 3
+#define PG_THREADS 512
+#define PG_PANEL_ELEMS (PG_BM * PG_K)      // 96 KiB of bf16
+#define PG_BTILE_ELEMS (PG_BN * PG_BK)     // 16 KiB of bf16
+#define PG_NKS (PG_K / PG_BK)              // 6 K-steps per N tile
+
+struct PGemmArgs {
+  const float* X;        // f32 [M][384] (LayerNorm fused) or null
+  const bf16_t* A;       // bf16 [M][lda] when X is null
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  const bf16_t* W;       // [N][384]
+  const float* bias;     // [N]
+  void* C;               // bf16 [M][ldc] (epi 0,1) or f32 [M][ldc] (epi 2)
+  int M, N, lda, ldc;
+  int qscale_cols;
+  float qscale;
+  int panels;
+};
+
+__device__ __forceinline__ void pg_glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+__device__ __forceinline__ float pg_gelu(float v) {   // exact-erf GELU, erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7)
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.f - poly * __expf(-x * x);
+  return 0.5f * v * (1.f + (v < 0.f ? -e : e));
+}
+
+// element offset of (row r, k) inside the LDS panel: 6 segments of 64 k (128 B) per row, 16-B chunk ^= r & 7
+__device__ __forceinline__ int panel_off(int r, int k) {
+  return r * PG_K + (k & ~63) + ((((k & 63) >> 3) ^ (r & 7)) << 3) + (k & 7);
+}
+
+template <int EPI, bool FUSE_LN>
+__global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* panel = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* ring = panel + PG_PANEL_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l16 = lane & 15, gq = lane >> 4;
+  const int wn = wv >> 1, wm = wv & 1;   // wave tile: 32 output columns (n) x 64 rows (m)
+  const int m0 = blockIdx.x * PG_BM;
+  const int ntiles = g.N / PG_BN;
+  const int total_steps = ntiles * PG_NKS;
+
+  // ---- weight stream: one wave-instruction = 8 rows (n) x 128 B; wave wv stages rows [wv*16, +16) of each tile
+  const int srow = lane >> 3, sslot = lane & 7;
+  const bf16_t* wsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wv * 16 + i * 8 + srow;
+    wsrc[i] = g.W + (int64_t)r * PG_K + ((sslot ^ (r & 7)) * 8);
+  }
+  auto stage = [&](int u) {   // virtual step u = tile * 6 + kstep -> ring slot u % 3
+    const int tn = u / PG_NKS, ks = u - tn * PG_NKS;
+    bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      pg_glds16(wsrc[i] + (int64_t)tn * PG_BN * PG_K + ks * PG_BK, lb + (wv * 16 + i * 8) * PG_BK + lane * 8);
+  };
+  stage(0);
+  stage(1);
+
+  // ---- build the activation panel
+  if constexpr (FUSE_LN) {
+    float2 gam[3], bet[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      gam[i] = reinterpret_cast<const float2*>(g.ln_g)[i * 64 + lane];
+      bet[i] = reinterpret_cast<const float2*>(g.ln_b)[i * 64 + lane];
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wv * 16 + rr;
+      int gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      const float2* xp = reinterpret_cast<const float2*>(g.X + (int64_t)gr * PG_K);
+      float2 v[3];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { v[i] = xp[i * 64 + lane]; s += v[i].x + v[i].y; }
+      const float mean = wave_sum(s) * (1.f / PG_K);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float a = v[i].x - mean, b = v[i].y - mean; q += a * a + b * b; }
+      const float rstd = rsqrtf(wave_sum(q) * (1.f / PG_K) + g.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int k = (i * 64 + lane) * 2;
+        const unsigned pk = pack_bf2((v[i].x - mean) * rstd * gam[i].x + bet[i].x, (v[i].y - mean) * rstd * gam[i].y + bet[i].y);
+        *reinterpret_cast<unsigned*>(panel + panel_off(r, k)) = pk;
+      }
+    }
+  } else {
+    // bf16 input: DMA, 8 rows x 128 B per wave-instruction; 16 row-groups x 6 segments = 96 pieces, 12 per wave
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+      const int piece = wv * 12 + p, rg = piece / 6, seg = piece % 6;
+      const int r = rg * 8 + srow;
+      int gr = m0 + r;
+      gr = gr < g.M ? gr : g.M - 1;
+      // lane-linear destination: row-group base + segment: rows are 768 B apart, so one instruction may only
+      // cover ONE row's 128-B segment per 8 lanes -> destination = panel + r*384 + seg*64 + sslot*8 is NOT linear
+      // across rows; stage through registers instead (16 B per lane), still full-line loads.
+      const uint4 val = *reinterpret_cast<const uint4*>(g.A + (int64_t)gr * g.lda + seg * 64 + ((sslot ^ (r & 7)) * 8));
+      *reinterpret_cast<uint4*>(panel + r * PG_K + seg * 64 + sslot * 8) = val;
+    }
+  }
+
+  // ---- fragment addressing.  A operand = weights (rows n), B operand = activations (rows m)
+  int rown[2], rowm[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) rown[a] = wn * 32 + a * 16 + l16;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) rowm[b] = wm * 64 + b * 16 + l16;
+  auto load_frags = [&](int u, int s, bf16x8 (&fw)[2], bf16x8 (&fx)[4]) {
+    const int ks = u % PG_NKS;
+    const bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const bf16x8*>(lb + rown[a] * PG_BK + (((s * 4 + gq) ^ (rown[a] & 7)) * 8));
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      fx[b] = *reinterpret_cast<const bf16x8*>(panel + rowm[b] * PG_K + ks * 64 + (((s * 4 + gq) ^ (rowm[b] & 7)) * 8));
+  };
+  f32x4 acc[2][4];
+  auto mfmas = [&](const bf16x8 (&fw)[2], const bf16x8 (&fx)[4]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) Mma<MODE_BF16>::mma(acc[a][b], fw[a], fx[b]);
+  };
+#define PG_USE(fw, fx)               \
+  __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]))
+
+  bf16x8 fw0[2], fx0[4], fw1[2], fx1[4];
+  __syncthreads();   // panel complete; also drains vmcnt(0): weight steps 0 and 1 are in LDS
+  load_frags(0, 0, fw0, fx0);
+  PG_USE(fw0, fx0);
+
+  int u = 0;
+  for (int tn = 0; tn < ntiles; ++tn) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < PG_NKS; ++ks, ++u) {
+      const bool issued = u + 2 < total_steps;
+      if (issued) stage(u + 2);        // slot of step u-1: its fragment reads retired before the last barrier
+      load_frags(u, 1, fw1, fx1);      // sub-step 1 reads under the MFMAs of sub-step 0
+      mfmas(fw0, fx0);
+      PG_USE(fw1, fx1);
+      if (u + 1 < total_steps) {
+        // step u+1 must be visible.  vmcnt counts in issue order: behind step u+1 sit this step's 2 DMA loads and,
+        // right after a tile boundary, the previous tile's epilogue traffic (8 stores / 8 loads + 8 stores) -- allow
+        // those to stay in flight.
+        if (ks == 0 && tn > 0) {
+          if constexpr (EPI == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (issued) {
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        load_frags(u + 1, 0, fw0, fx0);
+      }
+      mfmas(fw1, fx1);
+      if (u + 1 < total_steps) { PG_USE(fw0, fx0); }
+    }
+    // ---- epilogue of N tile tn, straight from registers: lane holds columns n0 + 4 gq + (0..3) of row m
+    const int nbase = tn * PG_BN + wn * 32;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int n = nbase + a * 16 + gq * 4;
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int m = m0 + rowm[b];
+        if (m < g.M) {
+          float v0 = acc[a][b][0] + bv.x, v1 = acc[a][b][1] + bv.y, v2 = acc[a][b][2] + bv.z, v3 = acc[a][b][3] + bv.w;
+          if constexpr (EPI == 2) {
+            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
+            const float4 res = *cp;
+            *cp = make_float4(res.x + v0, res.y + v1, res.z + v2, res.w + v3);
+          } else {
+            if constexpr (EPI == 1) {
+              v0 = pg_gelu(v0); v1 = pg_gelu(v1); v2 = pg_gelu(v2); v3 = pg_gelu(v3);
+            } else if (n < g.qscale_cols) {
+              v0 *= g.qscale; v1 *= g.qscale; v2 *= g.qscale; v3 *= g.qscale;
+            }
+            uint2 o;
+            o.x = pack_bf2(v0, v1);
+            o.y = pack_bf2(v2, v3);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
+                                     float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t M, int N,
+                                     int epilogue, int qscale_cols, float qscale, void* stream) {
+  MAAVSS_CHECK_ARG((X != nullptr) != (A != nullptr), "vit_panel_gemm: exactly one of X (f32, LayerNorm fused) and A (bf16) must be given");
+  MAAVSS_CHECK_ARG(W && bias && C && M > 0 && M < (1LL << 31), "vit_panel_gemm: bad arguments");
+  MAAVSS_CHECK_ARG(N % PG_BN == 0 && N >= PG_BN, "vit_panel_gemm: N must be a multiple of 128 (got %d)", N);
+  MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "vit_panel_gemm: unknown epilogue");
+  MAAVSS_CHECK_ARG(!X || (ln_gamma && ln_beta), "vit_panel_gemm: LayerNorm parameters missing");
+  MAAVSS_CHECK_ARG(X || (lda % 8 == 0 && lda >= PG_K), "vit_panel_gemm: lda must be a multiple of 8 and >= 384");
+  MAAVSS_CHECK_ARG(ldc % 4 == 0 && qscale_cols % 4 == 0, "vit_panel_gemm: ldc / qscale_cols must be multiples of 4");
+  PGemmArgs g;
+  g.X = X; g.A = (const bf16_t*)A; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
+  g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.M = (int)M; g.N = N; g.lda = lda; g.ldc = ldc;
+  g.qscale_cols = qscale_cols; g.qscale = qscale; g.panels = cdiv(M, PG_BM);
+  const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t);   // 144 KiB
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(g.panels), block(PG_THREADS);
+#define PG_LAUNCH(E, L)                                                                                              \
+  {                                                                                                                  \
+    static bool set = false;                                                                                         \
+    if (!set) {                                                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(vit_panel_gemm_kernel<E, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+      set = true;                                                                                                    \
+    }                                                                                                                \
+    hipLaunchKernelGGL((vit_panel_gemm_kernel<E, L>), grid, block, smem, st, g);                                     \
+  }
+  if (X) {
+    if (epilogue == 0) PG_LAUNCH(0, true) else if (epilogue == 1) PG_LAUNCH(1, true) else PG_LAUNCH(2, true)
+  } else {
+    if (epilogue == 0) PG_LAUNCH(0, false) else if (epilogue == 1) PG_LAUNCH(1, false) else PG_LAUNCH(2, false)
+  }
+#undef PG_LAUNCH
+  MAAVSS_LAUNCH_CHECK("vit_panel_gemm_kernel");
+  return MAAVSS_OK;
+}

@@ -104,6 +104,7 @@ class VideoAttention:
         self.checkpoint_key = "teacher"
         self.device = torch.device(device)
         self.frames_per_launch = frames_per_launch
+        self.fused_panel_gemm = os.environ.get("MAAVSS_VIT_PANEL_GEMM", "1") != "0"   # LN+GEMM panel kernel for K=384
         self.model = self.__load_model(path_to_weights)
         self._dev = None          # device-side weight images, built lazily
         self._tables = {}
@@ -177,19 +178,31 @@ class VideoAttention:
         call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, st)
         call("maavss_vit_gemm", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
              EPI_F32_ROWTABLE, 0, 1.0, st)
+        qs = 0.125 * 1.4426950408889634          # q *= log2(e)/sqrt(64): the attention kernels run softmax on exp2
         for i in range(DEPTH):
             b = wts[i]
-            call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
-            call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
-                 3 * DIM, DIM, EPI_BF16_BIAS, DIM, 0.125 * 1.4426950408889634, st)   # q *= log2(e)/sqrt(64): exp2 softmax
+            if self.fused_panel_gemm:
+                # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
+                call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
+                     ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rows, 3 * DIM, EPI_BF16_BIAS, DIM, qs, st)
+            else:
+                call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
+                call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
+                     3 * DIM, DIM, EPI_BF16_BIAS, DIM, qs, st)
             if i == DEPTH - 1:
                 break
             call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, st)
-            call("maavss_vit_gemm", ptr(att_o), DIM, ptr(b["proj_w"]), ptr(b["proj_b"]), None, 0, ptr(x), DIM, rows, DIM,
-                 DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
-            call("maavss_vit_layernorm", ptr(x), ptr(b["n2w"]), ptr(b["n2b"]), ptr(xn), rows, DIM, LN_EPS, st)
-            call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["fc1_w"]), ptr(b["fc1_b"]), None, 0, ptr(hid), MLP, rows, MLP, DIM,
-                 EPI_BF16_BIAS_GELU, 0, 1.0, st)
+            if self.fused_panel_gemm:
+                call("maavss_vit_panel_gemm", None, ptr(att_o), DIM, None, None, LN_EPS, ptr(b["proj_w"]), ptr(b["proj_b"]),
+                     ptr(x), DIM, rows, DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
+                call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n2w"]), ptr(b["n2b"]), LN_EPS, ptr(b["fc1_w"]),
+                     ptr(b["fc1_b"]), ptr(hid), MLP, rows, MLP, EPI_BF16_BIAS_GELU, 0, 1.0, st)
+            else:
+                call("maavss_vit_gemm", ptr(att_o), DIM, ptr(b["proj_w"]), ptr(b["proj_b"]), None, 0, ptr(x), DIM, rows,
+                     DIM, DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
+                call("maavss_vit_layernorm", ptr(x), ptr(b["n2w"]), ptr(b["n2b"]), ptr(xn), rows, DIM, LN_EPS, st)
+                call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["fc1_w"]), ptr(b["fc1_b"]), None, 0, ptr(hid), MLP, rows, MLP,
+                     DIM, EPI_BF16_BIAS_GELU, 0, 1.0, st)
             call("maavss_vit_gemm", ptr(hid), MLP, ptr(b["fc2_w"]), ptr(b["fc2_b"]), None, 0, ptr(x), DIM, rows, DIM, MLP,
                  EPI_F32_BIAS_RESID, 0, 1.0, st)
         att = torch.empty(f, HEADS, ntok - 1, device=dev, dtype=torch.float32)

@@ -59,6 +59,34 @@ def test_vit_gemm_epilogues(m, n, k):
     np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("m,n", [(1000, 1152), (785 * 2 + 3, 1536), (130, 384)])
+def test_vit_panel_gemm_fused_layernorm(m, n):
+    """LN + GEMM panel kernel (K = 384) against torch: LayerNorm in f32, operands rounded to bf16, f32 accumulate."""
+    k = 384
+    x = rnd(m, k, seed=1, scale=1.5) + 0.2
+    gam, bet = 1 + 0.1 * rnd(k, seed=2), 0.1 * rnd(k, seed=3)
+    w, bias = bf(rnd(n, k, seed=4, scale=k ** -0.5)), rnd(n, seed=5, scale=0.1)
+    xn = bf(F.layer_norm(x, (k,), gam, bet, 1e-6)).float()
+    z = xn @ w.float().t() + bias
+    xc, gc, bc, wc, biasc = x.cuda(), gam.cuda(), bet.cuda(), w.cuda(), bias.cuda()
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
+          c.data_ptr(), n, m, n, 0, 384, 0.125, _st())
+    want = z.clone()
+    want[:, :384] *= 0.125
+    np.testing.assert_allclose(c.float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
+          c.data_ptr(), n, m, n, 1, 0, 1.0, _st())
+    np.testing.assert_allclose(c.float().cpu().numpy(), F.gelu(z).numpy(), rtol=1.5e-2, atol=1.5e-2)
+    # bf16 input (no LayerNorm), f32 residual in place
+    a = bf(rnd(m, k, seed=6))
+    res = rnd(m, n, seed=7)
+    ac, rc = a.cuda(), res.clone().cuda()
+    _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, m, n,
+          2, 0, 1.0, _st())
+    np.testing.assert_allclose(rc.cpu().numpy(), (res + a.float() @ w.float().t() + bias).numpy(), rtol=1e-4, atol=3e-4)
+
+
 def test_vit_layernorm_and_patchify():
     rows = 1003
     x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
