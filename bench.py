@@ -210,6 +210,8 @@ def main():
         def flops_of(name, a):
             if name == "maavss_vit_gemm":
                 return 2.0 * a[8] * a[9] * a[10]                  # M, N, K
+            if name == "maavss_vit_panel_gemm":
+                return 2.0 * a[10] * a[11] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
             return 0.0
