@@ -393,6 +393,9 @@ __global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ partials, f
   }
 }
 
+int maavss_conv3d_wgrad_wide_try(const float* x, const float* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
+                                 int Wo, int c_in, int c_out, int pad, int mode, hipStream_t st);  // conv3d_wgrad_wide.hip
+
 extern "C" int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk) {
   return (int64_t)nchunk * 75 * c_in * c_out * 4;
 }
@@ -419,6 +422,14 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_wgrad: empty output");
   hipStream_t st = (hipStream_t)stream;
+  // the two large-M layers use the wide kernel (conv3d_wgrad_wide.hip): every tile staged once / three times
+  if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, st)) {
+    MAAVSS_LAUNCH_CHECK("conv3d_wgrad_wide_kernel");
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * c_in * c_out, 256)), dim3(256), 0, st, ws, dw, nchunk, c_in,
+                       c_out, beta);
+    MAAVSS_LAUNCH_CHECK("conv3d_wgrad_reduce_kernel");
+    return MAAVSS_OK;
+  }
 #define CASE(CI, CO)                                                                         \
   if (c_in == CI && c_out == CO) {                                                           \
     if (precise == MODE_F32) launch_wgrad<MODE_F32, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \

@@ -1,0 +1,162 @@
+// K8 (weight gradient), wide variant for the two large-M layers (Conv3d 16->32 and 32->64, reference
+// avse_model_final.py:39,44).  The first wgrad kernel (conv3d.hip) gives every (kd,kh) its own workgroup, so each
+// x / dy tile is pulled through L2 fifteen times (measured 14.3 GB fetched per launch for 16->32, MFMA busy 2 %).
+// Here one 512-thread workgroup owns KDN*25 taps: all 75 taps for 16->32 (KDN = 3), one kd for 32->64 (KDN = 1),
+// so a tile is staged once (resp. 3 times) and the 25..75 tap products run from the same LDS image:
+//   dW[tap][ci][co] += sum over the tile's 256 positions of x[pos + tap][ci] * dy[pos][co]
+// with the position as the MFMA K dimension, both operands read transposed from channels-last LDS tiles by
+// ds_read_b64_tr_b16.  Output: the same partial layout as the first kernel ([chunk][tap][ci][co]) for the common
+// deterministic reduce kernel.
+#include "mma.h"
+
+template <int MODE, int CI, int CO, int KDN>
+__global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ partials, int BT, int T, int H, int W,
+                                                               int Ho, int Wo, int pad, int tiles_x, int tiles_y,
+                                                               int tiles_per_chunk, int nchunk) {
+  using M = Mma<MODE>;
+  using E = typename M::elem;
+  constexpr int MT = CI / 16, NT = CO / 16, NTAP = KDN * 25, NPAIR = NTAP * MT, PW = (NPAIR + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  E* xs = reinterpret_cast<E*>(smem);        // [KDN][20 rows][20 cols][CI]
+  E* ds = xs + KDN * 400 * CI;               // [16][16][CO]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int G = lane >> 4, l16 = lane & 15;
+  constexpr int KDG = 3 / KDN;               // kd groups (blockIdx.x % KDG)
+  // XCD-aware mapping: the KDG blocks of one chunk take consecutive slots of one XCD (shared tiles hit its L2)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int chunk = (slot / KDG) * 8 + xcd, kdg = slot % KDG;
+  if (chunk >= nchunk) return;
+  const int kd0 = kdg * KDN;
+  f32x4 acc[PW][NT];
+#pragma unroll
+  for (int p = 0; p < PW; ++p)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int tile_beg = chunk * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y);
+    const int t = bt % T, x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    for (int i = tid; i < KDN * 400 * (CI / 4); i += 512) {
+      const int c4 = (i % (CI / 4)) * 4, pos = (i / (CI / 4)) % 400, kdl = i / ((CI / 4) * 400);
+      const int r = pos / 20, c = pos % 20;
+      const int tt = t + kd0 + kdl - 1, iy = y0 + r - pad, ix = x0 + c - pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CI + c4);
+      E* d = xs + (kdl * 400 + pos) * CI + c4;
+      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    }
+    const float* dp = dy + (int64_t)bt * Ho * Wo * CO;
+    for (int i = tid; i < 256 * (CO / 4); i += 512) {
+      const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
+      const int oy = y0 + pos / 16, ox = x0 + pos % 16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
+      E* d = ds + pos * CO + c4;
+      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < 8; ++ks) {
+      // K step = output rows 2ks, 2ks+1; k = 0..31 -> (row 2ks + k/16, col k%16)
+      typename M::frag fb[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (MODE == MODE_F32) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = 8 * G + e;
+            const float v = ds[((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + l16];
+            if (e < 4) fb[j].lo[e] = v; else fb[j].hi[e - 4] = v;
+          }
+        } else {
+          bf16x4 h[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int k = 8 * G + 4 * hh + (l16 >> 2);
+            const E* a = ds + ((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + (l16 & 3) * 4;
+            h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+          }
+          fb[j] = concat4(h[0], h[1]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        const int q = wv + 8 * p;
+        if (q < NPAIR) {  // wave-uniform
+          const int tap = q / MT, mi = q % MT;
+          const int kdl = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
+          const E* xb = xs + kdl * 400 * CI + mi * 16;
+          typename M::frag fa;
+          if constexpr (MODE == MODE_F32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int k = 8 * G + e;
+              const float v = xb[((2 * ks + (k >> 4) + kh) * 20 + (k & 15) + kw) * CI + l16];
+              if (e < 4) fa.lo[e] = v; else fa.hi[e - 4] = v;
+            }
+          } else {
+            bf16x4 h[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int k = 8 * G + 4 * hh + (l16 >> 2);
+              const E* a = xb + ((2 * ks + (k >> 4) + kh) * 20 + (k & 15) + kw) * CI + (l16 & 3) * 4;
+              h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+            }
+            fa = concat4(h[0], h[1]);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) M::mma(acc[p][j], fa, fb[j]);
+        }
+      }
+    }
+  }
+  // partials[chunk][tap = (kd*5+kh)*5+kw][ci][co]
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int q = wv + 8 * p;
+    if (q < NPAIR) {
+      const int tap = q / MT, mi = q % MT;
+      float* out = partials + (((int64_t)chunk * 75 + kd0 * 25 + tap) * CI + mi * 16 + G * 4) * CO;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(int64_t)r * CO + j * 16 + l16] = acc[p][j][r];
+    }
+  }
+}
+
+template <int MODE, int CI, int CO, int KDN>
+static void launch_wide(const float* x, const float* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
+                        int nchunk, hipStream_t st) {
+  using E = typename Mma<MODE>::elem;
+  const size_t smem = (KDN * 400 * CI + 256 * CO) * sizeof(E);
+  auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN>;
+  if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int tpc = cdiv(tiles_total, nchunk);
+  constexpr int KDG = 3 / KDN;
+  hipLaunchKernelGGL(kern, dim3(KDG * cdiv(nchunk, 8) * 8), dim3(512), smem, st, x, dy, ws, BT, T, H, W, Ho, Wo, pad, tiles_x,
+                     tiles_y, tpc, nchunk);
+}
+
+// returns 1 if this (c_in, c_out) pair is handled by the wide kernel (and launches it), 0 otherwise
+int maavss_conv3d_wgrad_wide_try(const float* x, const float* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
+                                 int Wo, int c_in, int c_out, int pad, int mode, hipStream_t st) {
+#define WIDE(CI, CO, KDN)                                                                                      \
+  if (c_in == CI && c_out == CO) {                                                                             \
+    if (mode == MODE_F32) launch_wide<MODE_F32, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \
+    else if (mode == MODE_F16) launch_wide<MODE_F16, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
+    else launch_wide<MODE_BF16, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);                      \
+    return 1;                                                                                                  \
+  }
+  WIDE(16, 32, 3)
+  WIDE(32, 64, 1)
+#undef WIDE
+  return 0;
+}

@@ -69,8 +69,14 @@ def conv3d_igemm(x, wt, c_out, pad, precise, want_stats=False):
     return y, part
 
 
-def wgrad_chunks(b, t, ho, wo):
+def wgrad_chunks(b, t, ho, wo, ci=64, co=64):
+    """Number of position chunks (= partial sums) of the weight-gradient kernels.  The wide kernel (16->32: one
+    workgroup per chunk, 32->64: three) needs more chunks than the 15-workgroups-per-chunk kernel to fill 256 CUs."""
     tiles = b * t * ((ho + 15) // 16) * ((wo + 15) // 16)
+    if (ci, co) == (16, 32):
+        return max(1, min(512, tiles // 2))
+    if (ci, co) == (32, 64):
+        return max(1, min(256, tiles // 2))
     return max(1, min(64, tiles // 4))
 
 
@@ -81,7 +87,7 @@ def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
     ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
     assert tuple(dy.shape) == (b, t, ho, wo, co)
     if nchunk is None:
-        nchunk = wgrad_chunks(b, t, ho, wo)
+        nchunk = wgrad_chunks(b, t, ho, wo, ci, co)
     ws = torch.empty(query("maavss_conv3d_wgrad_ws_bytes", ci, co, nchunk) // 4, device=x.device, dtype=torch.float32)
     if dw is None:
         dw = torch.empty(co, ci, 3, 5, 5, device=x.device, dtype=torch.float32)
