@@ -41,8 +41,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  // one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved) instead of two converts plus a shift/or
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 // Two 4 x 16-bit halves (e.g. two ds_read_b64_tr_b16 results) -> one 8 x 16-bit MFMA fragment, as a pure
