@@ -150,10 +150,12 @@ int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, 
 /* panel GEMM for the K = 384 layers with the preceding LayerNorm fused (dino Block: norm1->attn.qkv, attn.proj,
  * norm2->mlp.fc1): C = epilogue(LN(X)[M][384] . W[N][384]^T) when X (f32) is given, or A (bf16, [M][lda]) . W^T
  * otherwise; exactly one of X / A is non-null.  epilogue 0 / 1 / 2 as in maavss_vit_gemm (bf16+q-scale, bf16+GELU,
- * f32 residual in place).  N % 128 == 0, ldc % 4 == 0, qscale_cols % 4 == 0. */
+ * f32 residual in place).  N % 128 == 0, N <= 2048, ldc % 8 == 0, qscale_cols % 8 == 0.  C must be ALLOCATED with
+ * c_rows >= ceil(M/128)*128 rows: the register epilogue stores whole 128-row panels unguarded (rows >= M receive
+ * don't-care values) so that its counted DMA waits stay exact. */
 int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
-                          float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t M, int N,
-                          int epilogue, int qscale_cols, float qscale, void* stream);
+                          float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M,
+                          int N, int epilogue, int qscale_cols, float qscale, void* stream);
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
   };
   stage(0);
   stage(1);
+  // bias -> LDS once (the deferred epilogue slices then issue no VMEM loads of their own, which keeps the
+  // counted vmcnt waits of the DMA ring exact)
+  float* bias_s = reinterpret_cast<float*>(ring + PG_STAGES * PG_BTILE_ELEMS);
+  for (int i = tid; i < g.N; i += PG_THREADS) bias_s[i] = g.bias[i];
 
   // ---- build the activation panel
   if constexpr (FUSE_LN) {
@@ -178,74 +182,85 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
   load_frags(0, 0, fw0, fx0);
   PG_USE(fw0, fx0);
 
+  // ---- main loop.  The epilogue of N tile tn is DEFERRED: its accumulators are copied to `prev` and written out in
+  // four slices during K-steps 0..3 of tile tn+1, so the bias / GELU / convert VALU work and the stores run underneath
+  // this wave's (and its SIMD partner's) MFMAs instead of in a serialized phase of their own.
+  f32x4 prev[4][2];
+  int prev_tn = -1;
+  // slice idx in 0..3 -> (h = idx >> 1, b = idx & 1): the 8 columns n = 128 tn + 64 wn + 32 h + 8 gq + (0..7) of row m
+  auto epi_slice = [&](int idx, int tn) {
+    const int h = idx >> 1, b = idx & 1;
+    const int n = tn * PG_BN + wn * 64 + h * 32 + gq * 8;
+    const int m = m0 + rowm[b];
+    const float4 b0 = *reinterpret_cast<const float4*>(bias_s + n), b1 = *reinterpret_cast<const float4*>(bias_s + n + 4);  // LDS
+    float v[8] = {prev[2 * h][b][0] + b0.x, prev[2 * h][b][1] + b0.y, prev[2 * h][b][2] + b0.z, prev[2 * h][b][3] + b0.w,
+                  prev[2 * h + 1][b][0] + b1.x, prev[2 * h + 1][b][1] + b1.y, prev[2 * h + 1][b][2] + b1.z,
+                  prev[2 * h + 1][b][3] + b1.w};
+    // No row guard: C is allocated with ceil(M/128)*128 rows (checked by the launcher), so every lane issues
+    // every store and the counted vmcnt waits below stay exact.
+    if constexpr (EPI == 2) {
+      float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
+      const float4 r0 = cp[0], r1 = cp[1];
+      cp[0] = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
+      cp[1] = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
+    } else {
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pg_gelu(v[e]);
+      } else if (n < g.qscale_cols) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.qscale;
+      }
+      const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
+    }
+  };
+  // VMEM operations a slice issues per lane (for the counted vmcnt below): 1 store (bf16) or 2 loads + 2 stores (f32)
+  constexpr int EOPS = EPI == 2 ? 4 : 1;
+
   int u = 0;
   for (int tn = 0; tn < ntiles; ++tn) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool have_prev = prev_tn >= 0;
+#pragma unroll
     for (int ks = 0; ks < PG_NKS; ++ks, ++u) {
       const bool issued = u + 2 < total_steps;
       if (issued) stage(u + 2);        // slot of step u-1: its fragment reads retired before the last barrier
       load_frags(u, 1, fw1, fx1);      // sub-step 1 reads under the MFMAs of sub-step 0
       mfmas(fw0, fx0);
+      if (have_prev && ks < 4) epi_slice(ks, prev_tn);
       PG_USE(fw1, fx1);
       if (u + 1 < total_steps) {
-        // step u+1 must be visible.  vmcnt counts in issue order: behind step u+1 sit this step's 2 DMA loads and,
-        // right after a tile boundary, the previous tile's epilogue traffic (8 stores / 8 loads + 8 stores) -- allow
-        // those to stay in flight.
-        if (ks == 0 && tn > 0) {
-          if constexpr (EPI == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // 4 epilogue stores + 2 DMA loads
-        } else if (issued) {
-          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // step u+1 must be visible.  vmcnt counts in issue order: younger than step u+1's loads are this step's 2
+        // DMA loads plus the epilogue slices of this and of the previous K-step -- they may stay in flight.
+        const int slices = have_prev ? ((ks < 4 ? 1 : 0) + ((ks >= 1 && ks <= 4) ? 1 : 0)) : 0;
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (slices == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (slices == 1) { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         load_frags(u + 1, 0, fw0, fx0);
       }
       mfmas(fw1, fx1);
       if (u + 1 < total_steps) { PG_USE(fw0, fx0); }
     }
-    // ---- epilogue of N tile tn, straight from registers: per half h the lane holds the 8 columns
-    // n = 128 tn + 64 wn + 32 h + 8 gq + (0..7) of row m (tiles 2h and 2h+1, see rown[])
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = tn * PG_BN + wn * 64 + h * 32 + gq * 8;
-      const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int m = m0 + rowm[b];
-        if (m < g.M) {
-          float v[8] = {acc[2 * h][b][0] + b0.x, acc[2 * h][b][1] + b0.y, acc[2 * h][b][2] + b0.z, acc[2 * h][b][3] + b0.w,
-                        acc[2 * h + 1][b][0] + b1.x, acc[2 * h + 1][b][1] + b1.y, acc[2 * h + 1][b][2] + b1.z,
-                        acc[2 * h + 1][b][3] + b1.w};
-          if constexpr (EPI == 2) {
-            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
-            const float4 r0 = cp[0], r1 = cp[1];
-            cp[0] = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
-            cp[1] = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
-          } else {
-            if constexpr (EPI == 1) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = pg_gelu(v[e]);
-            } else if (n < g.qscale_cols) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= g.qscale;
-            }
-            const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
-          }
-        }
-      }
-    }
+      for (int b = 0; b < 2; ++b) prev[a][b] = acc[a][b];
+    prev_tn = tn;
   }
+  // flush the last tile's epilogue
+#pragma unroll
+  for (int idx = 0; idx < 4; ++idx) epi_slice(idx, prev_tn);
 }
 
 extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
-                                     float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t M, int N,
-                                     int epilogue, int qscale_cols, float qscale, void* stream) {
+                                     float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows,
+                                     int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* stream) {
   MAAVSS_CHECK_ARG((X != nullptr) != (A != nullptr), "vit_panel_gemm: exactly one of X (f32, LayerNorm fused) and A (bf16) must be given");
   MAAVSS_CHECK_ARG(W && bias && C && M > 0 && M < (1LL << 31), "vit_panel_gemm: bad arguments");
   MAAVSS_CHECK_ARG(N % PG_BN == 0 && N >= PG_BN, "vit_panel_gemm: N must be a multiple of 128 (got %d)", N);
@@ -253,11 +268,14 @@ extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, con
   MAAVSS_CHECK_ARG(!X || (ln_gamma && ln_beta), "vit_panel_gemm: LayerNorm parameters missing");
   MAAVSS_CHECK_ARG(X || (lda % 8 == 0 && lda >= PG_K), "vit_panel_gemm: lda must be a multiple of 8 and >= 384");
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && qscale_cols % 8 == 0, "vit_panel_gemm: ldc / qscale_cols must be multiples of 8");
+  MAAVSS_CHECK_ARG(c_rows >= (int64_t)cdiv(M, PG_BM) * PG_BM, "vit_panel_gemm: C needs ceil(M/128)*128 = %ld allocated rows (got %ld): stores are unguarded",
+                   (long)cdiv(M, PG_BM) * PG_BM, (long)c_rows);
   PGemmArgs g;
   g.X = X; g.A = (const bf16_t*)A; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
   g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.M = (int)M; g.N = N; g.lda = lda; g.ldc = ldc;
   g.qscale_cols = qscale_cols; g.qscale = qscale; g.panels = cdiv(M, PG_BM);
-  const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t);   // 144 KiB
+  MAAVSS_CHECK_ARG(N <= 2048, "vit_panel_gemm: N too large for the LDS bias image");
+  const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t) + (size_t)2048 * sizeof(float);   // 152 KiB
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(g.panels), block(PG_THREADS);
 #define PG_LAUNCH(E, L)                                                                                              \

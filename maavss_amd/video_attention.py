@@ -169,12 +169,13 @@ class VideoAttention:
         rows = f * ntok
         dev, st = frames.device, stream_ptr()
         wts, table = self._device_weights(), self._row_table(hp, wp)
+        rpad = (rows + 127) // 128 * 128      # the panel GEMM stores whole 128-row panels (include/maavss.h)
         a = torch.empty(rows, 192, device=dev, dtype=torch.bfloat16)
-        x = torch.empty(rows, DIM, device=dev, dtype=torch.float32)
-        xn = torch.empty(rows, DIM, device=dev, dtype=torch.bfloat16)
-        qkv = torch.empty(rows, 3 * DIM, device=dev, dtype=torch.bfloat16)
+        x = torch.empty(rpad, DIM, device=dev, dtype=torch.float32)
+        xn = torch.empty(rows, DIM, device=dev, dtype=torch.bfloat16) if not self.fused_panel_gemm else None
+        qkv = torch.empty(rpad, 3 * DIM, device=dev, dtype=torch.bfloat16)
         att_o = torch.empty(rows, DIM, device=dev, dtype=torch.bfloat16)
-        hid = torch.empty(rows, MLP, device=dev, dtype=torch.bfloat16)
+        hid = torch.empty(rpad, MLP, device=dev, dtype=torch.bfloat16)
         call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, st)
         call("maavss_vit_gemm", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
              EPI_F32_ROWTABLE, 0, 1.0, st)
@@ -184,7 +185,7 @@ class VideoAttention:
             if self.fused_panel_gemm:
                 # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
-                     ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rows, 3 * DIM, EPI_BF16_BIAS, DIM, qs, st)
+                     ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, 3 * DIM, EPI_BF16_BIAS, DIM, qs, st)
             else:
                 call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
                 call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
@@ -194,9 +195,9 @@ class VideoAttention:
             call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, st)
             if self.fused_panel_gemm:
                 call("maavss_vit_panel_gemm", None, ptr(att_o), DIM, None, None, LN_EPS, ptr(b["proj_w"]), ptr(b["proj_b"]),
-                     ptr(x), DIM, rows, DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
+                     ptr(x), DIM, rpad, rows, DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n2w"]), ptr(b["n2b"]), LN_EPS, ptr(b["fc1_w"]),
-                     ptr(b["fc1_b"]), ptr(hid), MLP, rows, MLP, EPI_BF16_BIAS_GELU, 0, 1.0, st)
+                     ptr(b["fc1_b"]), ptr(hid), MLP, rpad, rows, MLP, EPI_BF16_BIAS_GELU, 0, 1.0, st)
             else:
                 call("maavss_vit_gemm", ptr(att_o), DIM, ptr(b["proj_w"]), ptr(b["proj_b"]), None, 0, ptr(x), DIM, rows,
                      DIM, DIM, EPI_F32_BIAS_RESID, 0, 1.0, st)

@@ -69,22 +69,28 @@ def test_vit_panel_gemm_fused_layernorm(m, n):
     xn = bf(F.layer_norm(x, (k,), gam, bet, 1e-6)).float()
     z = xn @ w.float().t() + bias
     xc, gc, bc, wc, biasc = x.cuda(), gam.cuda(), bet.cuda(), w.cuda(), bias.cuda()
-    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    mp = (m + 127) // 128 * 128                       # outputs are allocated in whole 128-row panels
+    c = torch.empty(mp, n, dtype=torch.bfloat16, device="cuda")
     _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
-          c.data_ptr(), n, m, n, 0, 384, 0.125, _st())
+          c.data_ptr(), n, mp, m, n, 0, 384, 0.125, _st())
     want = z.clone()
     want[:, :384] *= 0.125
-    np.testing.assert_allclose(c.float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    np.testing.assert_allclose(c[:m].float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
     _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
-          c.data_ptr(), n, m, n, 1, 0, 1.0, _st())
-    np.testing.assert_allclose(c.float().cpu().numpy(), F.gelu(z).numpy(), rtol=1.5e-2, atol=1.5e-2)
+          c.data_ptr(), n, mp, m, n, 1, 0, 1.0, _st())
+    np.testing.assert_allclose(c[:m].float().cpu().numpy(), F.gelu(z).numpy(), rtol=1.5e-2, atol=1.5e-2)
     # bf16 input (no LayerNorm), f32 residual in place
     a = bf(rnd(m, k, seed=6))
     res = rnd(m, n, seed=7)
-    ac, rc = a.cuda(), res.clone().cuda()
-    _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, m, n,
-          2, 0, 1.0, _st())
-    np.testing.assert_allclose(rc.cpu().numpy(), (res + a.float() @ w.float().t() + bias).numpy(), rtol=1e-4, atol=3e-4)
+    ac = a.cuda()
+    rc = torch.zeros(mp, n, device="cuda")
+    rc[:m] = res.cuda()
+    _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, mp,
+          m, n, 2, 0, 1.0, _st())
+    np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + a.float() @ w.float().t() + bias).numpy(), rtol=1e-4, atol=3e-4)
+    with pytest.raises(Exception):                     # unpadded output is refused
+        _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n,
+              m - 1 if m % 128 == 0 else m, m, n, 2, 0, 1.0, _st())
 
 
 def test_vit_layernorm_and_patchify():
