@@ -211,7 +211,7 @@ def main():
             if name == "maavss_vit_gemm":
                 return 2.0 * a[8] * a[9] * a[10]                  # M, N, K
             if name == "maavss_vit_panel_gemm":
-                return 2.0 * a[10] * a[11] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
+                return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
             return 0.0
@@ -228,6 +228,19 @@ def main():
                             "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                             "share_of_kernel_time": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3)}
                 break
+        # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs of this same command; FETCH doubled per the gfx950 guide) -- null if absent.
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+        if roofline is not None and os.path.isfile(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            stem = roofline["kernel"].replace("maavss_", "") + "_kernel"
+            rows = [r for r in pmc["kernels"] if stem in r["kernel"]]
+            n = sum(r["launches"] for r in rows)
+            if n:
+                mb = sum(r["launches"] * (r["fetch_MB_per_launch_x2_corrected"] + r["write_MB_per_launch"]) for r in rows) / n
+                roofline["traffic"] = round(mb * 1e6)
+                roofline["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_hbm_traffic_latest.json)"
         breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:12]}
         if args.verbose:
             shapes = {}
