@@ -88,6 +88,9 @@ int maavss_bn_stats(const float* y, float* partials, int64_t rows, int C, void* 
 int maavss_bn_finalize(const float* partials, int nblk, int C, double count, float eps, float momentum, float* mean,
                        float* invstd, float* running_mean, float* running_var, void* num_batches_tracked,
                        float* ws /* nullable; 256*2*C floats enable the two-level reduction */, void* stream);
+/* eval mode (model.eval()): mean / invstd from the running statistics instead of the batch */
+int maavss_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd, int C,
+                         void* stream);
 int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C, int pool,
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
@@ -159,7 +162,7 @@ int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* l
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
-                         int clip_frames, void* stream);
+                         int clip_frames, int attn_diff /* av_dataset.py:323-326, needs clip_frames > 0 */, void* stream);
 
 /* ---- EXTENSION (no reference counterpart): AdaptiveAvgPool2d closing the STFT encoder for frame sizes the
  * reference constructor cannot build (224^2, 384^2; SURVEY.md finding 2).  x NHWC [B][H][W][C]; out/dout

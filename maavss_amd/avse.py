@@ -86,12 +86,15 @@ class _AVSEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x_a, x_v, *params):
         outs, saved = model._engine_forward(x_a, x_v, train=model.training)
-        ctx.model, ctx.saved = model, saved
+        ctx.model, ctx.saved, ctx.was_training = model, saved, model.training
         return outs
 
     @staticmethod
     def backward(ctx, d_a, d_v, d_fused):
         model = ctx.model
+        if not ctx.was_training:
+            raise _lib.MaavssError("backward through an eval-mode forward (running-statistics BatchNorm) is not built; "
+                                   "call model.train() for training steps")
         names = model._param_names
         need = {n: ctx.needs_input_grad[3 + i] for i, n in enumerate(names)}
         grads = model._engine_backward(ctx.saved, d_a, d_v, d_fused, need)
@@ -204,8 +207,7 @@ class AV_Fusion_Model_Frames(nn.Module):
         return self.stft_encoder[3 * i], self.stft_encoder[3 * i + 1]
 
     def _engine_forward(self, x_a, x_v, train=True):
-        if not train:
-            raise NotImplementedError("eval-mode BatchNorm (running statistics) is not part of the training hot path")
+        # train=False (model.eval()): BatchNorm uses its running statistics and leaves them untouched (forward only)
         pr = ops.MODE_F32 if self.precise else ops.MODE_F16     # forward conv operands: IEEE half (or exact f32)
         b, t, w = x_v.shape[0], self.t_v, self.width
         assert tuple(x_v.shape[1:]) == (1, t, w, w) and tuple(x_a.shape[1:]) == (2, self.t_a, self.n_bins)
@@ -221,13 +223,16 @@ class AV_Fusion_Model_Frames(nn.Module):
             conv, bn = self._vis(i)
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
             if i == 0:
-                y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=True)
+                y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=train)
             else:
                 wt = ops.conv3d_prep(conv.weight.detach(), 0, pr)
-                y, part = ops.conv3d_igemm(act_in, wt, co, pad, pr, want_stats=True)
+                y, part = ops.conv3d_igemm(act_in, wt, co, pad, pr, want_stats=train)
             hh, ww = y.shape[2], y.shape[3]
-            mean, invstd = ops.bn_finalize(part, b * t * hh * ww, bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked, bn.eps, bn.momentum)
+            if train:
+                mean, invstd = ops.bn_finalize(part, b * t * hh * ww, bn.running_mean, bn.running_var,
+                                               bn.num_batches_tracked, bn.eps, bn.momentum)
+            else:
+                mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             if i < 4:
                 out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
                 strides = None
@@ -246,9 +251,12 @@ class AV_Fusion_Model_Frames(nn.Module):
             conv, bn = self._aud(i)
             y = ops.conv2d_fwd(cur, conv.weight.detach(), st, pw, nchw)
             ho, wo = y.shape[1], y.shape[2]
-            part = ops.bn_stats(y, co)
-            mean, invstd = ops.bn_finalize(part, b * ho * wo, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                           bn.eps, bn.momentum)
+            if train:
+                part = ops.bn_stats(y, co)
+                mean, invstd = ops.bn_finalize(part, b * ho * wo, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                               bn.eps, bn.momentum)
+            else:
+                mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             y5 = y.view(b, 1, ho, wo, co)
             last = i == n_layers - 1
             if last and self._enc_pool is None:

@@ -300,6 +300,25 @@ extern "C" int maavss_bn_finalize(const float* partials, int nblk, int C, double
   return MAAVSS_OK;
 }
 
+// eval-mode BatchNorm: mean / invstd from the running statistics (model.eval(), torch.nn.BatchNorm semantics)
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd, int C) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    mean[c] = running_mean[c];
+    invstd[c] = rsqrtf(running_var[c] + eps);
+  }
+}
+
+extern "C" int maavss_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd,
+                                    int C, void* stream) {
+  MAAVSS_CHECK_ARG(running_mean && running_var && mean && invstd && C > 0 && C <= 64, "bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, running_mean, running_var, eps, mean,
+                     invstd, C);
+  MAAVSS_LAUNCH_CHECK("bn_eval_stats_kernel");
+  return MAAVSS_OK;
+}
+
 extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                                       const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C,
                                       int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,

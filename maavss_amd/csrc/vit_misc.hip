@@ -82,6 +82,27 @@ __global__ __launch_bounds__(256) void vit_maps_pass1_kernel(const float* __rest
   if (tid == 0) fmax[f] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// attn_diff option (av_dataset.py:323-326): within each clip, frame t becomes frame t minus frame t-1 and frame 0
+// becomes zero; the clip maximum (over the whole zero-padded canvas, hence >= 0) is stored in every fmax of the clip.
+__global__ __launch_bounds__(256) void vit_maps_diff_kernel(float* __restrict__ small, float* __restrict__ fmax, int n, int T) {
+  __shared__ float red[4];
+  const int64_t c0 = (int64_t)blockIdx.x * T;
+  float mx = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    for (int t = T - 1; t >= 1; --t) {
+      const float d = small[(c0 + t) * n + j] - small[(c0 + t - 1) * n + j];
+      small[(c0 + t) * n + j] = d;
+      mx = fmaxf(mx, d);
+    }
+    small[c0 * n + j] = 0.f;
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int t = threadIdx.x; t < T; t += 256) fmax[c0 + t] = mx;
+}
+
 // pass 2: out[f][0][y][x] = small[f][(y/8)*wp + x/8] * (1 / max over the clip's frames of fmax), zero outside the
 // patch grid.  clip_frames = 0 -> no clip normalisation (VideoAttention._inference alone).
 __global__ __launch_bounds__(256) void vit_maps_pass2_kernel(const float* __restrict__ small, const float* __restrict__ fmax,
@@ -133,16 +154,21 @@ extern "C" int maavss_vit_layernorm(const float* x, const float* gamma, const fl
 
 // ws: n_frames * (hp*wp + 1) floats
 extern "C" int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
-                                    int clip_frames, void* stream) {
+                                    int clip_frames, int attn_diff, void* stream) {
   MAAVSS_CHECK_ARG(att && out && ws && n_frames > 0 && heads > 0, "vit_attn_maps: bad arguments");
   MAAVSS_CHECK_ARG(W % 4 == 0 && H >= 8 && W >= 8, "vit_attn_maps: W must be a multiple of 4");
   MAAVSS_CHECK_ARG(clip_frames == 0 || n_frames % clip_frames == 0, "vit_attn_maps: n_frames must be a multiple of clip_frames");
+  MAAVSS_CHECK_ARG(!attn_diff || clip_frames > 0, "vit_attn_maps: attn_diff needs clip_frames > 0");
   const int hp = H / 8, wp = W / 8, n = hp * wp;
   float* small = ws;
   float* fmax = ws + n_frames * n;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vit_maps_pass1_kernel, dim3((unsigned)n_frames), dim3(256), 0, st, att, small, fmax, heads, n);
   MAAVSS_LAUNCH_CHECK("vit_maps_pass1_kernel");
+  if (attn_diff) {
+    hipLaunchKernelGGL(vit_maps_diff_kernel, dim3((unsigned)(n_frames / clip_frames)), dim3(256), 0, st, small, fmax, n, clip_frames);
+    MAAVSS_LAUNCH_CHECK("vit_maps_diff_kernel");
+  }
   const int64_t total4 = n_frames * H * (W / 4);
   hipLaunchKernelGGL(vit_maps_pass2_kernel, dim3((unsigned)((total4 + 255) / 256 > 16384 ? 16384 : (total4 + 255) / 256)),
                      dim3(256), 0, st, small, fmax, out, H, W, hp, wp, clip_frames, total4);

@@ -145,6 +145,15 @@ def bn_finalize(part, count, running_mean=None, running_var=None, num_batches_tr
     return mean, invstd
 
 
+def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
+    """eval-mode BatchNorm statistics (running mean / var) in the (mean, invstd) form the fused kernels take."""
+    _f32(running_mean, running_var)
+    mean, invstd = torch.empty_like(running_mean), torch.empty_like(running_mean)
+    call("maavss_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(invstd),
+         running_mean.numel(), stream_ptr())
+    return mean, invstd
+
+
 def cl_strides(t, hp, wp, c):
     """element strides (b, t, pos, c) of a channels-last pooled tensor [B,T,Hp,Wp,C]."""
     return (t * hp * wp * c, hp * wp * c, c, 1)

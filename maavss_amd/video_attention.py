@@ -210,9 +210,10 @@ class VideoAttention:
         call("maavss_vit_cls_attn", ptr(qkv), ptr(att), f, ntok, HEADS, 3 * DIM, st)
         return att
 
-    def attention_frames(self, frames, clip_frames=0, out=None):
+    def attention_frames(self, frames, clip_frames=0, out=None, attn_diff=False):
         """Batched GPU path: frames [F,3,H,W] -> attention frames [F,1,H,W] (each /frame max; with
-        clip_frames = T additionally /clip max over consecutive groups of T frames, av_dataset.py:328).
+        clip_frames = T additionally /clip max over consecutive groups of T frames, av_dataset.py:328;
+        attn_diff=True first replaces each clip's frames by their temporal difference, av_dataset.py:323-326).
         Frames are processed `frames_per_launch` at a time (bounds the activation scratch: ~9.6 MB per frame at
         224^2); measured on MI355X, fewer and larger launches win (512 frames/group: 75 ms/step vs 88 ms at 64)."""
         _lib.require_cuda(frames)
@@ -228,7 +229,7 @@ class VideoAttention:
             att = self.cls_attention(frames[s:e])
             ws = torch.empty((e - s) * (hp * wp + 1), device=frames.device, dtype=torch.float32)
             call("maavss_vit_attn_maps", ptr(att), ptr(out[s:e]), ptr(ws), e - s, HEADS, h, w, int(clip_frames),
-                 stream_ptr())
+                 int(bool(attn_diff)), stream_ptr())
         return out
 
     def _inference(self, frames):

@@ -147,6 +147,25 @@ def test_adaptive_extension_224_matches_oracle():
         assert (p.grad.cpu() - gr).norm().item() <= 3e-3 * gr.norm().item() + 1e-7, k
 
 
+def test_eval_mode_uses_running_statistics():
+    """model.eval(): BatchNorm with running statistics, buffers untouched, matches the oracle twin in eval()."""
+    from oracle import avse_ref_cpu as orc
+    m = dict(batch=2, frames=8, width=128, fft_len=256, hops_per_frame=8, seed=13)
+    model, twin, (x_a, x_v, _, _) = _build(m, precise=True)
+    orc.load_seeded(twin, m["seed"])
+    twin.eval()
+    model.eval()
+    before = {k: v.clone() for k, v in model.named_buffers()}
+    with torch.no_grad():
+        a_ref, v_ref, f_ref = twin(x_a, x_v)
+        a, v, f = model(x_a.cuda(), x_v.cuda())
+    np.testing.assert_allclose(a.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(f.cpu().numpy(), f_ref.numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), rtol=0, atol=3e-5)
+    for k, b in model.named_buffers():
+        assert torch.equal(b, before[k]), k
+
+
 def test_reference_constructor_guards():
     import maavss_amd
     with pytest.raises(ValueError):

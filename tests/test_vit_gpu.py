@@ -136,12 +136,28 @@ def test_attn_maps_postprocess():
     out = torch.empty(f, 1, hp * 8 + 4, wp * 8, device="cuda")
     ws = torch.empty(f * (hp * wp + 1), device="cuda")
     attc = att.cuda()
-    _call("maavss_vit_attn_maps", attc.data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8 + 4, wp * 8, 3, _st())
+    _call("maavss_vit_attn_maps", attc.data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8 + 4, wp * 8, 3, 0, _st())
     want = torch.zeros(f, 1, hp * 8 + 4, wp * 8)
     for c in range(2):
         fr = vref.attention_frames_from_cls(att[3 * c:3 * c + 3], hp, wp)
         want[3 * c:3 * c + 3, :, :hp * 8] = vref.clip_normalise_ref(fr).permute(1, 0, 2, 3)
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_attn_maps_temporal_diff():
+    """attn_diff=True path (av_dataset.py:323-326) against the oracle's clip_normalise_ref(attn_diff=True)."""
+    from oracle import vit_ref_cpu as vref
+    f, hp, wp = 8, 3, 4
+    att = torch.rand(f, 6, hp * wp, generator=torch.Generator().manual_seed(4))
+    out = torch.empty(f, 1, hp * 8, wp * 8, device="cuda")
+    ws = torch.empty(f * (hp * wp + 1), device="cuda")
+    attc = att.cuda()
+    _call("maavss_vit_attn_maps", attc.data_ptr(), out.data_ptr(), ws.data_ptr(), f, 6, hp * 8, wp * 8, 4, 1, _st())
+    want = torch.zeros(f, 1, hp * 8, wp * 8)
+    for c in range(2):
+        fr = vref.attention_frames_from_cls(att[4 * c:4 * c + 4], hp, wp)
+        want[4 * c:4 * c + 4] = vref.clip_normalise_ref(fr, attn_diff=True).permute(1, 0, 2, 3)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("width,frames", [(64, 4), (224, 2)])
