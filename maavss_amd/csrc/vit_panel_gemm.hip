@@ -187,13 +187,9 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
   // this wave's (and its SIMD partner's) MFMAs instead of in a serialized phase of their own.
   f32x4 prev[4][2];
   int prev_tn = -1;
-  // slice idx in 0..3 -> (b = idx >> 1, h = idx & 1): the 8 columns n = 128 tn + 64 wn + 32 h + 8 gq + (0..7) of row
-  // m0 + rowm[b].  bf16 outputs: the h = 0 slice only converts; the h = 1 slice swaps one 16-B piece with lane l^8
-  // (DPP row_ror:8, no LDS) so that each of its two store instructions writes 8 rows x 128 contiguous bytes (full
-  // lines) instead of 16 rows x 64 B.
-  uint4 hold = make_uint4(0, 0, 0, 0);
+  // slice idx in 0..3 -> (h = idx >> 1, b = idx & 1): the 8 columns n = 128 tn + 64 wn + 32 h + 8 gq + (0..7) of row m
   auto epi_slice = [&](int idx, int tn) {
-    const int b = idx >> 1, h = idx & 1;
+    const int h = idx >> 1, b = idx & 1;
     const int n = tn * PG_BN + wn * 64 + h * 32 + gq * 8;
     const int m = m0 + rowm[b];
     const float4 b0 = *reinterpret_cast<const float4*>(bias_s + n), b1 = *reinterpret_cast<const float4*>(bias_s + n + 4);  // LDS
@@ -216,26 +212,11 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
         for (int e = 0; e < 8; ++e) v[e] *= g.qscale;
       }
       const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-      if (h == 0) {
-        hold = o;
-      } else {
-        const bool low = l16 < 8;
-        const uint4 send = low ? o : hold;     // low lanes give away their h=1 piece, high lanes their h=0 piece
-        uint4 recv;
-        recv.x = __builtin_amdgcn_update_dpp(0u, send.x, 0x128, 0xf, 0xf, false);   // row_ror:8 = swap with lane l^8
-        recv.y = __builtin_amdgcn_update_dpp(0u, send.y, 0x128, 0xf, 0xf, false);
-        recv.z = __builtin_amdgcn_update_dpp(0u, send.z, 0x128, 0xf, 0xf, false);
-        recv.w = __builtin_amdgcn_update_dpp(0u, send.w, 0x128, 0xf, 0xf, false);
-        const int row_a = m0 + wm * 32 + b * 16 + (l16 & 7);          // store A: rows +0..7, store B: rows +8..15
-        const int col = tn * PG_BN + wn * 64 + (low ? 0 : 32) + gq * 8;
-        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (int64_t)row_a * g.ldc + col;
-        *reinterpret_cast<uint4*>(cp) = low ? hold : recv;
-        *reinterpret_cast<uint4*>(cp + (int64_t)8 * g.ldc) = low ? recv : o;
-      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
     }
   };
-  // VMEM operations per lane of the slice run in K-step ks (for the counted vmcnt below)
-  auto slice_ops = [&](int ks) -> int { return ks < 0 || ks > 3 ? 0 : (EPI == 2 ? 4 : ((ks & 1) ? 2 : 0)); };
+  // VMEM operations a slice issues per lane (for the counted vmcnt below): 1 store (bf16) or 2 loads + 2 stores (f32)
+  constexpr int EOPS = EPI == 2 ? 4 : 1;
 
   int u = 0;
   for (int tn = 0; tn < ntiles; ++tn) {
@@ -255,12 +236,11 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
       if (u + 1 < total_steps) {
         // step u+1 must be visible.  vmcnt counts in issue order: younger than step u+1's loads are this step's 2
         // DMA loads plus the epilogue slices of this and of the previous K-step -- they may stay in flight.
-        const int young = have_prev ? 2 + slice_ops(ks) + slice_ops(ks - 1) : 2;   // 2, 4, 6 or 10
+        const int slices = have_prev ? ((ks < 4 ? 1 : 0) + ((ks >= 1 && ks <= 4) ? 1 : 0)) : 0;
         if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (young == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (slices == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (slices == 1) { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         load_frags(u + 1, 0, fw0, fx0);
       }
