@@ -19,7 +19,8 @@
 #define PG_BN 128
 #define PG_BK 64
 #define PG_STAGES 3
-#define PG_THREADS 512
+#define PG_THREADS 576                     // 8 MFMA waves + 1 weight-stream (DMA) wave
+#define PG_MMA_WAVES 8
 #define PG_PANEL_ELEMS (PG_BM * PG_K)      // 96 KiB of bf16
 #define PG_BTILE_ELEMS (PG_BN * PG_BK)     // 16 KiB of bf16
 #define PG_NKS (PG_K / PG_BK)              // 6 K-steps per N tile
@@ -44,12 +45,23 @@ __device__ __forceinline__ void pg_glds16(const void* g, void* lds) {
                                    (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-__device__ __forceinline__ float pg_gelu(float v) {   // exact-erf GELU, erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7)
-  const float x = fabsf(v) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.f + 0.3275911f * x);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.f - poly * __expf(-x * x);
-  return 0.5f * v * (1.f + (v < 0.f ? -e : e));
+// GELU for two accumulator values at a time.  gelu(v) = v * Phi(v), with Phi(v) - 1/2 = v * Q(v^2) on |v| <= 4.2 (Q: degree-7
+// minimax fit constrained to Phi(+-4.2) = 1 / 0, so clamping the ARGUMENT is all that is needed outside) -- max |error| vs the
+// exact-erf GELU 9.3e-5 over all v, an order of magnitude below the bf16 rounding of the stored value for |gelu| > 0.05.
+// No transcendental, 11 full-rate instructions per PAIR (v_pk_mul/v_pk_fma): the erf form it replaces (rcp + exp + 9 FMAs per
+// element) made fc1 VALU-bound at twice its MFMA time.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pg_gelu2(v2f v) {
+  const v2f vc = {__builtin_amdgcn_fmed3f(v.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v.y, -4.2f, 4.2f)};
+  const v2f u = vc * vc;
+  v2f q = u * -9.018102001e-10f + 7.941707090e-08f;
+  q = q * u + -3.038026629e-06f;
+  q = q * u + 6.689195681e-05f;
+  q = q * u + -9.506666631e-04f;
+  q = q * u + 9.298265605e-03f;
+  q = q * u + -6.552827696e-02f;
+  q = q * u + 3.984659427e-01f;
+  return v * (vc * q + 0.5f);
 }
 
 // element offset of (row r, k) inside the LDS panel: 6 segments of 64 k (128 B) per row, 16-B chunk ^= r & 7
@@ -58,7 +70,7 @@ __device__ __forceinline__ int panel_off(int r, int k) {
 }
 
 template <int EPI, bool FUSE_LN>
-__global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs g) {
+__global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* panel = reinterpret_cast<bf16_t*>(smem);
   bf16_t* ring = panel + PG_PANEL_ELEMS;
@@ -69,27 +81,39 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
   const int ntiles = g.N / PG_BN;
   const int total_steps = ntiles * PG_NKS;
 
-  // ---- weight stream: one wave-instruction = 8 rows (n) x 128 B; wave wv stages rows [wv*16, +16) of each tile
+  // ---- weight stream: owned by wave 8 alone.  vmcnt retires in issue order, so a wave that both stores outputs
+  // and waits for its DMA loads has to wait for the acknowledgement of every older store first -- with the stream
+  // spread over the MFMA waves each K-step stalled on the write latency of the previous epilogue slice.  The DMA
+  // wave issues the whole [128 n x 64 k] tile of a step (16 wave-instructions of 8 rows x 128 B), waits for its own
+  // loads only and publishes them through the per-step barrier; the MFMA waves never wait on vmcnt.
   const int srow = lane >> 3, sslot = lane & 7;
-  const bf16_t* wsrc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wv * 16 + i * 8 + srow;
-    wsrc[i] = g.W + (int64_t)r * PG_K + ((sslot ^ (r & 7)) * 8);
-  }
+  const bf16_t* wsrc = g.W + (int64_t)srow * PG_K + ((sslot ^ srow) * 8);
   auto stage = [&](int u) {   // virtual step u = tile * 6 + kstep -> ring slot u % 3
     const int tn = u / PG_NKS, ks = u - tn * PG_NKS;
-    bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS;
+    bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS + lane * 8;
+    const bf16_t* src = wsrc + (int64_t)tn * PG_BN * PG_K + ks * PG_BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      pg_glds16(wsrc[i] + (int64_t)tn * PG_BN * PG_K + ks * PG_BK, lb + (wv * 16 + i * 8) * PG_BK + lane * 8);
+    for (int i = 0; i < 16; ++i) pg_glds16(src + i * 8 * PG_K, lb + i * 8 * PG_BK);
   };
-  stage(0);
-  stage(1);
-  // bias -> LDS once (the deferred epilogue slices then issue no VMEM loads of their own, which keeps the
-  // counted vmcnt waits of the DMA ring exact)
   float* bias_s = reinterpret_cast<float*>(ring + PG_STAGES * PG_BTILE_ELEMS);
-  for (int i = tid; i < g.N; i += PG_THREADS) bias_s[i] = g.bias[i];
+  if (wv == PG_MMA_WAVES) {
+    stage(0);
+    stage(1);
+    for (int i = lane; i < g.N; i += 64) bias_s[i] = g.bias[i];   // bias -> LDS once
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // matches the "panel complete" barrier of the MFMA waves
+    for (int u = 0; u + 1 < total_steps; ++u) {
+      // slot of step u+2 == slot of step u-1: its fragment reads retired before the barrier that ended step u-1
+      if (u + 2 < total_steps) {
+        stage(u + 2);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // step u+1 landed; step u+2 may stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
 
   // ---- build the activation panel
   if constexpr (FUSE_LN) {
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
   asm volatile("" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]))
 
   bf16x8 fw0[4], fx0[2], fw1[4], fx1[2];
-  __syncthreads();   // panel complete; also drains vmcnt(0): weight steps 0 and 1 are in LDS
+  __syncthreads();   // panel complete; the DMA wave arrives here with weight steps 0 and 1 and the bias in LDS
   load_frags(0, 0, fw0, fx0);
   PG_USE(fw0, fx0);
 
@@ -196,8 +220,7 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
     float v[8] = {prev[2 * h][b][0] + b0.x, prev[2 * h][b][1] + b0.y, prev[2 * h][b][2] + b0.z, prev[2 * h][b][3] + b0.w,
                   prev[2 * h + 1][b][0] + b1.x, prev[2 * h + 1][b][1] + b1.y, prev[2 * h + 1][b][2] + b1.z,
                   prev[2 * h + 1][b][3] + b1.w};
-    // No row guard: C is allocated with ceil(M/128)*128 rows (checked by the launcher), so every lane issues
-    // every store and the counted vmcnt waits below stay exact.
+    // No row guard: C is allocated with ceil(M/128)*128 rows (checked by the launcher).
     if constexpr (EPI == 2) {
       float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
       const float4 r0 = cp[0], r1 = cp[1];
@@ -206,7 +229,11 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
     } else {
       if constexpr (EPI == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = pg_gelu(v[e]);
+        for (int e = 0; e < 8; e += 2) {
+          const v2f ge = pg_gelu2(v2f{v[e], v[e + 1]});
+          v[e] = ge.x;
+          v[e + 1] = ge.y;
+        }
       } else if (n < g.qscale_cols) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g.qscale;
@@ -215,8 +242,6 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
     }
   };
-  // VMEM operations a slice issues per lane (for the counted vmcnt below): 1 store (bf16) or 2 loads + 2 stores (f32)
-  constexpr int EOPS = EPI == 2 ? 4 : 1;
 
   int u = 0;
   for (int tn = 0; tn < ntiles; ++tn) {
@@ -227,20 +252,12 @@ __global__ __launch_bounds__(PG_THREADS, 2) void vit_panel_gemm_kernel(PGemmArgs
     const bool have_prev = prev_tn >= 0;
 #pragma unroll
     for (int ks = 0; ks < PG_NKS; ++ks, ++u) {
-      const bool issued = u + 2 < total_steps;
-      if (issued) stage(u + 2);        // slot of step u-1: its fragment reads retired before the last barrier
       load_frags(u, 1, fw1, fx1);      // sub-step 1 reads under the MFMAs of sub-step 0
       mfmas(fw0, fx0);
       if (have_prev && ks < 4) epi_slice(ks, prev_tn);
       PG_USE(fw1, fx1);
       if (u + 1 < total_steps) {
-        // step u+1 must be visible.  vmcnt counts in issue order: younger than step u+1's loads are this step's 2
-        // DMA loads plus the epilogue slices of this and of the previous K-step -- they may stay in flight.
-        const int slices = have_prev ? ((ks < 4 ? 1 : 0) + ((ks >= 1 && ks <= 4) ? 1 : 0)) : 0;
-        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (slices == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (slices == 1) { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-        else { if constexpr (EOPS == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        // step u+1 is published by the DMA wave through this barrier; stores of the epilogue slices stay in flight
         __builtin_amdgcn_s_barrier();
         load_frags(u + 1, 0, fw0, fx0);
       }
