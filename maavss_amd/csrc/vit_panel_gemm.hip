@@ -3,27 +3,32 @@
 // video_attention.py:52).  Why a second GEMM kernel: at K = 384 the tiled kernel (vit_gemm.hip) is bound by the
 // L2 -> LDS feed (48 KiB of operands per 256x128x64 step) and by epilogues that nothing overlaps.  Here the
 // activation panel is STATIONARY:
-//   * a workgroup (8 waves) owns 128 rows; the whole [128 x 384] bf16 panel lives in LDS (96 KiB) and is built once
-//     -- either by LayerNorm-ing the f32 residual rows on the way in (one wave per row, wave reductions; the
-//     normalised tensor never exists in HBM and the LayerNorm kernel disappears), or by DMA for a bf16 input;
-//   * only the weights stream: [128 n x 64 k] tiles (16 KiB, L2-resident) through a 3-slot global_load_lds ring
-//     that runs continuously over all N tiles of the panel -- a third of the staged bytes per FLOP;
+//   * a workgroup owns 128 rows; the whole [128 x 384] bf16 panel lives in LDS (96 KiB) and is built once -- either
+//     by LayerNorm-ing the f32 residual rows on the way in (one wave per row, wave reductions; the normalised tensor
+//     never exists in HBM and the LayerNorm kernel disappears), or by copying a bf16 input;
+//   * only the weights stream (128 FLOP per staged byte): [128 n x 32 k] tiles (8 KiB, L2-resident) through an
+//     8-slot global_load_lds ring that fills the remaining 64 KiB of LDS and runs continuously over all N tiles of
+//     the panel.  The ring is issued by a dedicated ninth wave and kept SIX steps (48 KiB) ahead: the L2 -> LDS
+//     path answers after ~1300 clocks under load (s_memtime stamps), so the bytes in flight, not the MFMA rate,
+//     set the speed of this loop;
 //   * the MFMA roles are swapped (weights = A operand, activations = B operand), so an accumulator lane holds
-//     4 CONSECUTIVE output columns of one row: the epilogue stores 8 B (bf16) / 16 B (f32 read-modify-write)
-//     straight from registers -- no LDS staging, no barrier, and other waves' MFMAs keep running underneath.
+//     4 CONSECUTIVE output columns of one row: the epilogue stores 16 B straight from registers, deferred by one
+//     N tile and sliced under the next tile's MFMAs.
 // Epilogues: 0 +bias, q-scale -> bf16 | 1 +bias, GELU -> bf16 | 2 +bias +residual -> f32 in place.
 #include "mma.h"
 
 #define PG_K 384
 #define PG_BM 128
 #define PG_BN 128
-#define PG_BK 64
-#define PG_STAGES 3
-#define PG_THREADS 576                     // 8 MFMA waves + 1 weight-stream (DMA) wave
+#define PG_BK 32
+#define PG_STAGES 8
+#define PG_AHEAD 6                         // ring steps in flight beyond the one being published
 #define PG_MMA_WAVES 8
+#define PG_LOADERS 4                       // weight-stream (LDS-DMA) waves, one per SIMD
+#define PG_THREADS ((PG_MMA_WAVES + PG_LOADERS) * 64)
 #define PG_PANEL_ELEMS (PG_BM * PG_K)      // 96 KiB of bf16
-#define PG_BTILE_ELEMS (PG_BN * PG_BK)     // 16 KiB of bf16
-#define PG_NKS (PG_K / PG_BK)              // 6 K-steps per N tile
+#define PG_BTILE_ELEMS (PG_BN * PG_BK)     // 8 KiB of bf16
+#define PG_NKS (PG_K / PG_BK)              // 12 K-steps per N tile
 
 struct PGemmArgs {
   const float* X;        // f32 [M][384] (LayerNorm fused) or null
@@ -51,17 +56,19 @@ __device__ __forceinline__ void pg_glds16(const void* g, void* lds) {
 // No transcendental, 11 full-rate instructions per PAIR (v_pk_mul/v_pk_fma): the erf form it replaces (rcp + exp + 9 FMAs per
 // element) made fc1 VALU-bound at twice its MFMA time.
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pg_gelu2(v2f v) {
-  const v2f vc = {__builtin_amdgcn_fmed3f(v.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(v.y, -4.2f, 4.2f)};
-  const v2f u = vc * vc;
-  v2f q = u * -9.018102001e-10f + 7.941707090e-08f;
-  q = q * u + -3.038026629e-06f;
-  q = q * u + 6.689195681e-05f;
-  q = q * u + -9.506666631e-04f;
-  q = q * u + 9.298265605e-03f;
-  q = q * u + -6.552827696e-02f;
-  q = q * u + 3.984659427e-01f;
-  return v * (vc * q + 0.5f);
+__device__ __forceinline__ void pg_gelu4(v2f& a, v2f& b) {   // two independent Horner chains, interleaved
+  const v2f ca = {__builtin_amdgcn_fmed3f(a.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(a.y, -4.2f, 4.2f)};
+  const v2f cb = {__builtin_amdgcn_fmed3f(b.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(b.y, -4.2f, 4.2f)};
+  const v2f ua = ca * ca, ub = cb * cb;
+  v2f qa = ua * -9.018102001e-10f + 7.941707090e-08f, qb = ub * -9.018102001e-10f + 7.941707090e-08f;
+  constexpr float kC[6] = {-3.038026629e-06f, 6.689195681e-05f, -9.506666631e-04f, 9.298265605e-03f, -6.552827696e-02f, 3.984659427e-01f};
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    qa = qa * ua + kC[c];
+    qb = qb * ub + kC[c];
+  }
+  a = a * (ca * qa + 0.5f);
+  b = b * (cb * qb + 0.5f);
 }
 
 // element offset of (row r, k) inside the LDS panel: 6 segments of 64 k (128 B) per row, 16-B chunk ^= r & 7
@@ -76,44 +83,50 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   bf16_t* ring = panel + PG_PANEL_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l16 = lane & 15, gq = lane >> 4;
-  const int wn = wv >> 2, wm = wv & 3;   // wave tile: 64 output columns (n) x 32 rows (m)
+  const int wn = (wv >> 2) & 1, wm = wv & 3;   // wave tile: 64 output columns (n) x 32 rows (m)
   const int m0 = blockIdx.x * PG_BM;
   const int ntiles = g.N / PG_BN;
   const int total_steps = ntiles * PG_NKS;
 
-  // ---- weight stream: owned by wave 8 alone.  vmcnt retires in issue order, so a wave that both stores outputs
-  // and waits for its DMA loads has to wait for the acknowledgement of every older store first -- with the stream
-  // spread over the MFMA waves each K-step stalled on the write latency of the previous epilogue slice.  The DMA
-  // wave issues the whole [128 n x 64 k] tile of a step (16 wave-instructions of 8 rows x 128 B), waits for its own
-  // loads only and publishes them through the per-step barrier; the MFMA waves never wait on vmcnt.
-  const int srow = lane >> 3, sslot = lane & 7;
-  const bf16_t* wsrc = g.W + (int64_t)srow * PG_K + ((sslot ^ srow) * 8);
-  auto stage = [&](int u) {   // virtual step u = tile * 6 + kstep -> ring slot u % 3
+  // ---- weight stream: four dedicated loader waves (one per SIMD), two 1-KiB pieces each per step.  Dedicated
+  // because (1) vmcnt retires in issue order -- a wave that both stores outputs and waits for DMA loads waits for the
+  // acknowledgement of every older store first -- and (2) one global_load_lds wave-instruction costs its wave ~60
+  // issue cycles (stamped: a single loader wave tops out at 17 B/clk, half of what the MFMAs consume), cycles that
+  // must not come out of the MFMA waves' instruction streams.  The loaders wait for their own loads only and publish
+  // them through the per-step barrier.  One step = [128 n x 32 k] = 8 pieces of 16 rows x 64 B.  LDS row r (64 B =
+  // four 16-B chunks) holds source chunk c at position c ^ ((r >> 2) & 3): the swizzle is applied on the global side
+  // (the LDS side of the DMA is lane-linear) and makes the ds_read_b128 fragment reads conflict-free.
+  const int srow = lane >> 2, schunk = lane & 3;
+  const int lw = wv - PG_MMA_WAVES;   // loader index (negative on MFMA waves)
+  const bf16_t* wsrc = g.W + (int64_t)(srow + lw * 32) * PG_K + ((schunk ^ ((srow >> 2) & 3)) * 8);
+  auto stage = [&](int u) {   // virtual step u = tile * 12 + kstep -> ring slot u % 8; this loader's rows [32 lw, +32)
     const int tn = u / PG_NKS, ks = u - tn * PG_NKS;
-    bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS + lane * 8;
+    bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS + lw * 32 * PG_BK + lane * 8;
     const bf16_t* src = wsrc + (int64_t)tn * PG_BN * PG_K + ks * PG_BK;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) pg_glds16(src + i * 8 * PG_K, lb + i * 8 * PG_BK);
+    for (int i = 0; i < 2; ++i) pg_glds16(src + i * 16 * PG_K, lb + i * 16 * PG_BK);
   };
-  float* bias_s = reinterpret_cast<float*>(ring + PG_STAGES * PG_BTILE_ELEMS);
-  if (wv == PG_MMA_WAVES) {
-    stage(0);
-    stage(1);
-    for (int i = lane; i < g.N; i += 64) bias_s[i] = g.bias[i];   // bias -> LDS once
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // matches the "panel complete" barrier of the MFMA waves
+  if (wv >= PG_MMA_WAVES) {
+    // steps 0 .. AHEAD go out at once; iteration u then issues step u+1+AHEAD into the slot freed by barrier u-1
+    // (step u-1's fragment reads retired before it) and waits until step u+1 has landed: vmcnt counts the 2
+    // instructions of each of the AHEAD younger steps.
+#pragma unroll
+    for (int u = 0; u <= PG_AHEAD; ++u)
+      if (u < total_steps) stage(u);
+    if (total_steps > PG_AHEAD) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // matches the "panel complete" barrier of the MFMA waves; step 0 is in LDS
     for (int u = 0; u + 1 < total_steps; ++u) {
-      // slot of step u+2 == slot of step u-1: its fragment reads retired before the barrier that ended step u-1
-      if (u + 2 < total_steps) {
-        stage(u + 2);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // step u+1 landed; step u+2 may stay in flight
+      if (u + 1 + PG_AHEAD < total_steps) {
+        stage(u + 1 + PG_AHEAD);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: nothing new goes out, drain
       }
       __builtin_amdgcn_s_barrier();
     }
     return;
   }
+  static_assert(PG_AHEAD * 2 == 12 && PG_AHEAD + 2 <= PG_STAGES, "vmcnt immediates above assume 6 steps x 2 instructions");
 
   // ---- build the activation panel
   if constexpr (FUSE_LN) {
@@ -157,18 +170,18 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
       }
     }
   } else {
-    // bf16 input: DMA, 8 rows x 128 B per wave-instruction; 16 row-groups x 6 segments = 96 pieces, 12 per wave
+    // bf16 input: 8 rows x 128 B per wave-instruction; 16 row-groups x 6 segments = 96 pieces, 12 per wave.  Rows are
+    // 768 B apart in the panel, so a lane-linear LDS-DMA destination cannot cover them: staged through registers
+    // (16 B per lane), still full-line loads.
+    const int prow = lane >> 3, pslot = lane & 7;
 #pragma unroll
     for (int p = 0; p < 12; ++p) {
       const int piece = wv * 12 + p, rg = piece / 6, seg = piece % 6;
-      const int r = rg * 8 + srow;
+      const int r = rg * 8 + prow;
       int gr = m0 + r;
       gr = gr < g.M ? gr : g.M - 1;
-      // lane-linear destination: row-group base + segment: rows are 768 B apart, so one instruction may only
-      // cover ONE row's 128-B segment per 8 lanes -> destination = panel + r*384 + seg*64 + sslot*8 is NOT linear
-      // across rows; stage through registers instead (16 B per lane), still full-line loads.
-      const uint4 val = *reinterpret_cast<const uint4*>(g.A + (int64_t)gr * g.lda + seg * 64 + ((sslot ^ (r & 7)) * 8));
-      *reinterpret_cast<uint4*>(panel + r * PG_K + seg * 64 + sslot * 8) = val;
+      const uint4 val = *reinterpret_cast<const uint4*>(g.A + (int64_t)gr * g.lda + seg * 64 + ((pslot ^ (r & 7)) * 8));
+      *reinterpret_cast<uint4*>(panel + r * PG_K + seg * 64 + pslot * 8) = val;
     }
   }
 
@@ -181,14 +194,19 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   for (int a = 0; a < 4; ++a) rown[a] = wn * 64 + (a >> 1) * 32 + (l16 >> 2) * 8 + (a & 1) * 4 + (l16 & 3);
 #pragma unroll
   for (int b = 0; b < 2; ++b) rowm[b] = wm * 32 + b * 16 + l16;
-  auto load_frags = [&](int u, int s, bf16x8 (&fw)[4], bf16x8 (&fx)[2]) {
-    const int ks = u % PG_NKS;
+  int woff[4], xoff[2];   // per-lane element offsets inside a ring slot / inside a 64-k segment pair of the panel
+#pragma unroll
+  for (int a = 0; a < 4; ++a) woff[a] = rown[a] * PG_BK + ((gq ^ ((rown[a] >> 2) & 3)) * 8);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) xoff[b] = rowm[b] * PG_K;
+  auto load_frags = [&](int u, bf16x8 (&fw)[4], bf16x8 (&fx)[2]) {
+    const int ks = u % PG_NKS;   // 32-k step: 64-k segment ks >> 1, chunks (ks & 1) * 4 + gq of it
     const bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const bf16x8*>(lb + rown[a] * PG_BK + (((s * 4 + gq) ^ (rown[a] & 7)) * 8));
+    for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const bf16x8*>(lb + woff[a]);
 #pragma unroll
     for (int b = 0; b < 2; ++b)
-      fx[b] = *reinterpret_cast<const bf16x8*>(panel + rowm[b] * PG_K + ks * 64 + (((s * 4 + gq) ^ (rowm[b] & 7)) * 8));
+      fx[b] = *reinterpret_cast<const bf16x8*>(panel + xoff[b] + (ks >> 1) * 64 + ((((ks & 1) * 4 + gq) ^ (rowm[b] & 7)) * 8));
   };
   f32x4 acc[4][2];
   auto mfmas = [&](const bf16x8 (&fw)[4], const bf16x8 (&fx)[2]) {
@@ -203,42 +221,44 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 
   bf16x8 fw0[4], fx0[2], fw1[4], fx1[2];
   __syncthreads();   // panel complete; the DMA wave arrives here with weight steps 0 and 1 and the bias in LDS
-  load_frags(0, 0, fw0, fx0);
-  PG_USE(fw0, fx0);
+  load_frags(0, fw0, fx0);
 
   // ---- main loop.  The epilogue of N tile tn is DEFERRED: its accumulators are copied to `prev` and written out in
-  // four slices during K-steps 0..3 of tile tn+1, so the bias / GELU / convert VALU work and the stores run underneath
+  // four slices during K-steps 0, 2, 4, 6 of tile tn+1, so the bias / GELU / convert VALU work and the stores run underneath
   // this wave's (and its SIMD partner's) MFMAs instead of in a serialized phase of their own.
   f32x4 prev[4][2];
   int prev_tn = -1;
   // slice idx in 0..3 -> (h = idx >> 1, b = idx & 1): the 8 columns n = 128 tn + 64 wn + 32 h + 8 gq + (0..7) of row m
+  v2f pbias[2][4];   // bias of the deferred tile: [h][pair] = columns n0 + 64 wn + 32 h + 8 gq + (0..7); no LDS left for it
+  auto load_bias = [&](int tn) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4* bp = reinterpret_cast<const float4*>(g.bias + tn * PG_BN + wn * 64 + h * 32 + gq * 8);
+      const float4 b0 = bp[0], b1 = bp[1];
+      pbias[h][0] = v2f{b0.x, b0.y}; pbias[h][1] = v2f{b0.z, b0.w}; pbias[h][2] = v2f{b1.x, b1.y}; pbias[h][3] = v2f{b1.z, b1.w};
+    }
+  };
   auto epi_slice = [&](int idx, int tn) {
     const int h = idx >> 1, b = idx & 1;
     const int n = tn * PG_BN + wn * 64 + h * 32 + gq * 8;
     const int m = m0 + rowm[b];
-    const float4 b0 = *reinterpret_cast<const float4*>(bias_s + n), b1 = *reinterpret_cast<const float4*>(bias_s + n + 4);  // LDS
-    float v[8] = {prev[2 * h][b][0] + b0.x, prev[2 * h][b][1] + b0.y, prev[2 * h][b][2] + b0.z, prev[2 * h][b][3] + b0.w,
-                  prev[2 * h + 1][b][0] + b1.x, prev[2 * h + 1][b][1] + b1.y, prev[2 * h + 1][b][2] + b1.z,
-                  prev[2 * h + 1][b][3] + b1.w};
+    v2f v[4] = {v2f{prev[2 * h][b][0], prev[2 * h][b][1]} + pbias[h][0], v2f{prev[2 * h][b][2], prev[2 * h][b][3]} + pbias[h][1],
+                v2f{prev[2 * h + 1][b][0], prev[2 * h + 1][b][1]} + pbias[h][2], v2f{prev[2 * h + 1][b][2], prev[2 * h + 1][b][3]} + pbias[h][3]};
     // No row guard: C is allocated with ceil(M/128)*128 rows (checked by the launcher).
     if constexpr (EPI == 2) {
       float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n);
       const float4 r0 = cp[0], r1 = cp[1];
-      cp[0] = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
-      cp[1] = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
+      cp[0] = make_float4(r0.x + v[0].x, r0.y + v[0].y, r0.z + v[1].x, r0.w + v[1].y);
+      cp[1] = make_float4(r1.x + v[2].x, r1.y + v[2].y, r1.z + v[3].x, r1.w + v[3].y);
     } else {
       if constexpr (EPI == 1) {
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const v2f ge = pg_gelu2(v2f{v[e], v[e + 1]});
-          v[e] = ge.x;
-          v[e + 1] = ge.y;
-        }
+        pg_gelu4(v[0], v[1]);
+        pg_gelu4(v[2], v[3]);
       } else if (n < g.qscale_cols) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g.qscale;
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * g.qscale;
       }
-      const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      const uint4 o = make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
     }
   };
@@ -251,24 +271,29 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool have_prev = prev_tn >= 0;
 #pragma unroll
-    for (int ks = 0; ks < PG_NKS; ++ks, ++u) {
-      load_frags(u, 1, fw1, fx1);      // sub-step 1 reads under the MFMAs of sub-step 0
+    for (int ks = 0; ks < PG_NKS; ks += 2, u += 2) {
+      // even step: fragments in (fw0, fx0); the reads of step u+1 go out under its MFMAs
+      PG_USE(fw0, fx0);                      // step u's fragment reads retired -> its ring slot may be refilled
+      __builtin_amdgcn_s_barrier();          // ... after this barrier, which also publishes step u+1
+      load_frags(u + 1, fw1, fx1);
+      __builtin_amdgcn_sched_barrier(0);     // the reads go out BEFORE the MFMA / epilogue block (hipcc sinks them below it otherwise)
       mfmas(fw0, fx0);
-      if (have_prev && ks < 4) epi_slice(ks, prev_tn);
+      if (have_prev && ks < 8) epi_slice(ks >> 1, prev_tn);
+      // odd step
       PG_USE(fw1, fx1);
-      if (u + 1 < total_steps) {
-        // step u+1 is published by the DMA wave through this barrier; stores of the epilogue slices stay in flight
+      if (u + 2 < total_steps) {
         __builtin_amdgcn_s_barrier();
-        load_frags(u + 1, 0, fw0, fx0);
+        load_frags(u + 2, fw0, fx0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       mfmas(fw1, fx1);
-      if (u + 1 < total_steps) { PG_USE(fw0, fx0); }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) prev[a][b] = acc[a][b];
     prev_tn = tn;
+    load_bias(tn);   // L2-resident; first used a K-step later
   }
   // flush the last tile's epilogue
 #pragma unroll
@@ -285,14 +310,13 @@ extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, con
   MAAVSS_CHECK_ARG(!X || (ln_gamma && ln_beta), "vit_panel_gemm: LayerNorm parameters missing");
   MAAVSS_CHECK_ARG(X || (lda % 8 == 0 && lda >= PG_K), "vit_panel_gemm: lda must be a multiple of 8 and >= 384");
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && qscale_cols % 8 == 0, "vit_panel_gemm: ldc / qscale_cols must be multiples of 8");
-  MAAVSS_CHECK_ARG(c_rows >= (int64_t)cdiv(M, PG_BM) * PG_BM, "vit_panel_gemm: C needs ceil(M/128)*128 = %ld allocated rows (got %ld): stores are unguarded",
-                   (long)cdiv(M, PG_BM) * PG_BM, (long)c_rows);
+  MAAVSS_CHECK_ARG(c_rows >= (int64_t)cdiv(M, 128) * 128, "vit_panel_gemm: C needs ceil(M/128)*128 = %ld allocated rows (got %ld): stores are unguarded",
+                   (long)cdiv(M, 128) * 128, (long)c_rows);
   PGemmArgs g;
   g.X = X; g.A = (const bf16_t*)A; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
   g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.M = (int)M; g.N = N; g.lda = lda; g.ldc = ldc;
   g.qscale_cols = qscale_cols; g.qscale = qscale; g.panels = cdiv(M, PG_BM);
-  MAAVSS_CHECK_ARG(N <= 2048, "vit_panel_gemm: N too large for the LDS bias image");
-  const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t) + (size_t)2048 * sizeof(float);   // 152 KiB
+  const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t);   // 96 + 64 = 160 KiB: all of a CU's LDS
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(g.panels), block(PG_THREADS);
 #define PG_LAUNCH(E, L)                                                                                              \
