@@ -22,7 +22,6 @@
 #define PG_BN 128
 #define PG_BK 32
 #define PG_STAGES 8
-#define PG_AHEAD 6                         // ring steps in flight beyond the one being published
 #define PG_MMA_WAVES 8
 #define PG_LOADERS 4                       // weight-stream (LDS-DMA) waves, one per SIMD
 #define PG_THREADS ((PG_MMA_WAVES + PG_LOADERS) * 64)
@@ -107,18 +106,21 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
     for (int i = 0; i < 2; ++i) pg_glds16(src + i * 16 * PG_K, lb + i * 16 * PG_BK);
   };
   if (wv >= PG_MMA_WAVES) {
-    // steps 0 .. AHEAD go out at once; iteration u then issues step u+1+AHEAD into the slot freed by barrier u-1
-    // (step u-1's fragment reads retired before it) and waits until step u+1 has landed: vmcnt counts the 2
-    // instructions of each of the AHEAD younger steps.
+    // Publication and slot release work on PAIRS of steps (one barrier per 64 k): pair P = steps 2P, 2P+1 lives in
+    // ring slots (2P, 2P+1) mod 8.  Pairs 0..2 go out at once; iteration P then issues pair P+3 into the slots freed
+    // by barrier P-1 (pair P-1's fragment reads retired before it) and waits until pair P+1 has landed: vmcnt counts
+    // the 4 instructions of each of the 2 younger pairs.
+    const int total_pairs = total_steps / 2;
 #pragma unroll
-    for (int u = 0; u <= PG_AHEAD; ++u)
-      if (u < total_steps) stage(u);
-    if (total_steps > PG_AHEAD) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // matches the "panel complete" barrier of the MFMA waves; step 0 is in LDS
-    for (int u = 0; u + 1 < total_steps; ++u) {
-      if (u + 1 + PG_AHEAD < total_steps) {
-        stage(u + 1 + PG_AHEAD);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    for (int pp = 0; pp < 3; ++pp)
+      if (pp < total_pairs) { stage(2 * pp); stage(2 * pp + 1); }
+    if (total_pairs > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // matches the "panel complete" barrier of the MFMA waves; pair 0 is in LDS
+    for (int pp = 0; pp + 1 < total_pairs; ++pp) {
+      if (pp + 3 < total_pairs) {
+        stage(2 * pp + 6);
+        stage(2 * pp + 7);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: nothing new goes out, drain
       }
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
     }
     return;
   }
-  static_assert(PG_AHEAD * 2 == 12 && PG_AHEAD + 2 <= PG_STAGES, "vmcnt immediates above assume 6 steps x 2 instructions");
+  static_assert(PG_STAGES == 8 && PG_NKS % 2 == 0, "pair-granular ring: 4 pairs of slots");
 
   // ---- build the activation panel
   if constexpr (FUSE_LN) {
@@ -272,14 +274,13 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
     const bool have_prev = prev_tn >= 0;
 #pragma unroll
     for (int ks = 0; ks < PG_NKS; ks += 2, u += 2) {
-      // even step: fragments in (fw0, fx0); the reads of step u+1 go out under its MFMAs
-      PG_USE(fw0, fx0);                      // step u's fragment reads retired -> its ring slot may be refilled
-      __builtin_amdgcn_s_barrier();          // ... after this barrier, which also publishes step u+1
+      // even step of the pair: fragments in (fw0, fx0); the odd step is already published, its reads go out at once
+      PG_USE(fw0, fx0);
       load_frags(u + 1, fw1, fx1);
       __builtin_amdgcn_sched_barrier(0);     // the reads go out BEFORE the MFMA / epilogue block (hipcc sinks them below it otherwise)
       mfmas(fw0, fx0);
       if (have_prev && ks < 8) epi_slice(ks >> 1, prev_tn);
-      // odd step
+      // odd step: once its fragments are in registers the pair's slots are free -> barrier, which publishes the next pair
       PG_USE(fw1, fx1);
       if (u + 2 < total_steps) {
         __builtin_amdgcn_s_barrier();
