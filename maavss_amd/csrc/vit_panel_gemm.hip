@@ -75,6 +75,75 @@ __device__ __forceinline__ int panel_off(int r, int k) {
   return r * PG_K + (k & ~63) + ((((k & 63) >> 3) ^ (r & 7)) << 3) + (k & 7);
 }
 
+// Wave-wide f32 sum on the VALU (DPP), result uniform.  The __shfl_xor form goes through the LDS crossbar: six
+// dependent ds_bpermute round trips, ~500 cycles per reduction -- stamped at 1000 cycles per LayerNorm row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pg_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float pg_wave_sum(float v) {
+  v += pg_dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += pg_dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += pg_dpp<0x141, 0xf>(v);   // row_half_mirror
+  v += pg_dpp<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v += pg_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v += pg_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// LayerNorm the NP row PAIRS [r0, r0 + 2 NP) of the panel that starts at global row m0, one wave.  Two consecutive rows
+// are 768 contiguous floats = three 16-byte-per-lane loads (j = 0: row A [4l, +4); j = 1: lanes < 32 row A [256 + 4l, +4),
+// lanes >= 32 row B [4(l-32), +4); j = 2: row B [128 + 4l, +4)): half the vector-memory instructions of an 8-byte-per-lane
+// sweep (the issue of 42 such loads per wave, twelve waves at once, was stamped at 8-13 k cycles per panel).  All 3 NP
+// loads go out before the first reduction, so the wave pays ONE memory latency.
+template <int NP>
+__device__ __forceinline__ void pg_ln_rows(const PGemmArgs& g, bf16_t* panel, int m0, int r0, int lane) {
+  const bool lo = lane < 32;
+  const int kj[3] = {4 * lane, lo ? 256 + 4 * lane : 4 * (lane - 32), 128 + 4 * lane};
+  float4 gam[3], bet[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    gam[j] = *reinterpret_cast<const float4*>(g.ln_g + kj[j]);
+    bet[j] = *reinterpret_cast<const float4*>(g.ln_b + kj[j]);
+  }
+  float4 v[NP][3];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    const int gr = m0 + r0 + 2 * pp;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int row = gr + (j == 0 ? 0 : j == 2 ? 1 : (lo ? 0 : 1));
+      row = row < g.M ? row : g.M - 1;   // rows past the end repeat the last one (their outputs land in C's padding rows)
+      v[pp][j] = *reinterpret_cast<const float4*>(g.X + (int64_t)row * PG_K + kj[j]);
+    }
+  }
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    auto sum4 = [](const float4& a) __attribute__((always_inline)) { return (a.x + a.y) + (a.z + a.w); };
+    const float s0 = sum4(v[pp][0]), s1 = sum4(v[pp][1]), s2 = sum4(v[pp][2]);
+    const float meanA = pg_wave_sum(s0 + (lo ? s1 : 0.f)) * (1.f / PG_K);
+    const float meanB = pg_wave_sum(s2 + (lo ? 0.f : s1)) * (1.f / PG_K);
+    const float mean[3] = {meanA, lo ? meanA : meanB, meanB};
+    float4 c[3];
+    float q[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      c[j] = make_float4(v[pp][j].x - mean[j], v[pp][j].y - mean[j], v[pp][j].z - mean[j], v[pp][j].w - mean[j]);
+      q[j] = (c[j].x * c[j].x + c[j].y * c[j].y) + (c[j].z * c[j].z + c[j].w * c[j].w);
+    }
+    const float rstdA = rsqrtf(pg_wave_sum(q[0] + (lo ? q[1] : 0.f)) * (1.f / PG_K) + g.ln_eps);
+    const float rstdB = rsqrtf(pg_wave_sum(q[2] + (lo ? 0.f : q[1])) * (1.f / PG_K) + g.ln_eps);
+    const float rstd[3] = {rstdA, lo ? rstdA : rstdB, rstdB};
+    const int row[3] = {r0 + 2 * pp, r0 + 2 * pp + (lo ? 0 : 1), r0 + 2 * pp + 1};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const uint2 o = make_uint2(pack_bf2(c[j].x * rstd[j] * gam[j].x + bet[j].x, c[j].y * rstd[j] * gam[j].y + bet[j].y),
+                                 pack_bf2(c[j].z * rstd[j] * gam[j].z + bet[j].z, c[j].w * rstd[j] * gam[j].w + bet[j].w));
+      *reinterpret_cast<uint2*>(panel + panel_off(row[j], kj[j])) = o;
+    }
+  }
+}
+
 template <int EPI, bool FUSE_LN>
 __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,7 +183,12 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp)
       if (pp < total_pairs) { stage(2 * pp); stage(2 * pp + 1); }
-    if (total_pairs > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (FUSE_LN) {
+      pg_ln_rows<2>(g, panel, m0, 112 + lw * 4, lane);     // its loads retire behind the DMA pieces: everything has landed after it
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      if (total_pairs > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();          // matches the "panel complete" barrier of the MFMA waves; pair 0 is in LDS
     for (int pp = 0; pp + 1 < total_pairs; ++pp) {
       if (pp + 3 < total_pairs) {
@@ -132,45 +206,9 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 
   // ---- build the activation panel
   if constexpr (FUSE_LN) {
-    float2 gam[3], bet[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      gam[i] = reinterpret_cast<const float2*>(g.ln_g)[i * 64 + lane];
-      bet[i] = reinterpret_cast<const float2*>(g.ln_b)[i * 64 + lane];
-    }
-    // 8 rows at a time: all 24 loads of a group are issued before the first reduction, so the group costs one
-    // memory latency instead of eight (measured: 22 us per panel with a row-at-a-time loop)
-#pragma unroll
-    for (int grp = 0; grp < 2; ++grp) {
-      float2 v[8][3];
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        int gr = m0 + wv * 16 + grp * 8 + rr;
-        gr = gr < g.M ? gr : g.M - 1;
-        const float2* xp = reinterpret_cast<const float2*>(g.X + (int64_t)gr * PG_K);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) v[rr][i] = xp[i * 64 + lane];
-      }
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int r = wv * 16 + grp * 8 + rr;
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) s += v[rr][i].x + v[rr][i].y;
-        const float mean = wave_sum(s) * (1.f / PG_K);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { const float a = v[rr][i].x - mean, b = v[rr][i].y - mean; q += a * a + b * b; }
-        const float rstd = rsqrtf(wave_sum(q) * (1.f / PG_K) + g.ln_eps);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int k = (i * 64 + lane) * 2;
-          const unsigned pk = pack_bf2((v[rr][i].x - mean) * rstd * gam[i].x + bet[i].x,
-                                       (v[rr][i].y - mean) * rstd * gam[i].y + bet[i].y);
-          *reinterpret_cast<unsigned*>(panel + panel_off(r, k)) = pk;
-        }
-      }
-    }
+    // all twelve waves build the panel, each in a single round of loads: 14 rows per MFMA wave, 4 per loader wave
+    // (the loaders first have their 12 ring pieces to issue; stamped, this split lets all waves arrive together)
+    pg_ln_rows<7>(g, panel, m0, wv * 14, lane);
   } else {
     // bf16 input: 8 rows x 128 B per wave-instruction; 16 row-groups x 6 segments = 96 pieces, 12 per wave.  Rows are
     // 768 B apart in the panel, so a lane-linear LDS-DMA destination cannot cover them: staged through registers
