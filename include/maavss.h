@@ -110,6 +110,20 @@ int maavss_conv2d_wgrad_nchunk(int B, int Ho, int Wo, int Ci, int Co);
 int maavss_conv2d_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Ci, int H, int W, int Co,
                         int sh, int sw, int pw, int in_layout, int beta, void* stream);
 
+/* ---- K11 ConvTranspose2d(k=(3,kw), kw in {9,10}, stride (sh,sw), padding (1,4), output_padding (oph,opw), bias=False)
+ * -- the STFT decoder, avse_model_final.py:155-193 (audio_ae_forward :254-256) ----
+ * x / dx NHWC [B][Hi][Wi][Ci]; w [Ci][Co][3][kw] (reference layout); y / dy [B][Ho][Wo][Co] for out_layout 1 or the
+ * network's NCHW [B][Co][Ho][Wo] for out_layout 0 (last decoder layer); Ho = (Hi-1) sh + 1 + oph, Wo = (Wi-1) sw - 8 + kw + opw.
+ * wgrad ws: maavss_convt2d_wgrad_nchunk(B,Hi,Wi) * Ci*Co*3*kw floats; beta 1 accumulates into dw. */
+int maavss_convt2d_out_size(int Hi, int Wi, int kw, int sh, int sw, int oph, int opw, int* Ho, int* Wo);
+int maavss_convt2d_fwd(const float* x, const float* w, float* y, int B, int Ci, int Hi, int Wi, int Co, int kw, int sh, int sw,
+                       int oph, int opw, int out_layout, void* stream);
+int maavss_convt2d_dgrad(const float* dy, const float* w, float* dx, int B, int Ci, int Hi, int Wi, int Co, int kw, int sh,
+                         int sw, int oph, int opw, int out_layout, void* stream);
+int maavss_convt2d_wgrad_nchunk(int B, int Hi, int Wi);
+int maavss_convt2d_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Ci, int Hi, int Wi, int Co, int kw,
+                         int sh, int sw, int oph, int opw, int out_layout, int beta, void* stream);
+
 /* ---- K12 bidirectional LSTM recurrence (hidden 256, no bias) -- avse_model_final.py:132-133,242 ----
  * gx [B][L][2][4][256] = X.W_ih^T (both directions, gate order i,f,g,o); av [B][L][512]; hp [B][L][2][256];
  * gs [B][L][2][4][256]; cs [B][L][2][256]; bwd: dav [B][L][512] -> dgx (same shape as gx), dc scratch [2][B][256]. */
