@@ -215,16 +215,38 @@ def main():
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
             return 0.0
+        def bytes_of(name, a):
+            """Algorithmic HBM bytes of one launch: every operand read once, every result written once."""
+            if name == "maavss_vit_gemm":
+                m, n, k, epi = a[8], a[9], a[10], a[11]
+                out = {2: 8.0, 3: 4.0}.get(epi, 2.0)                # f32 read-modify-write / f32 / bf16
+                return 2.0 * m * k + 2.0 * n * k + out * m * n
+            if name == "maavss_vit_panel_gemm":
+                m, n, epi = a[11], a[12], a[13]
+                return m * 384 * (4.0 if a[0] else 2.0) + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n
+            if name == "maavss_vit_attn":
+                return a[2] * a[3] * (1152 + 384) * 2.0             # qkv in, attention output out, bf16
+            return 0.0
         by_time = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
         dom_name, dom = by_time[0]
         roofline = None
         for name, d in by_time:
             fl = sum(flops_of(name, a) for a in d["args"])
             if fl > 0:
+                by = sum(bytes_of(name, a) for a in d["args"])
                 avg_ms = d["ms"] / d["calls"]
-                achieved = fl / d["calls"] / (avg_ms * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                tf = fl / d["calls"] / (avg_ms * 1e-3) / 1e12
+                gbs = by / d["calls"] / (avg_ms * 1e-3) / 1e9
+                # the binding roof is the one under which this launch would take longer (K = 384 layers: 230 FLOP per
+                # algorithmic byte, below the chip's 2500 / 8 = 312 FLOP/B -> HBM; attention: 400 FLOP/B -> MFMA)
+                hbm_bound = by / (PEAK_HBM_GBS * 1e9) > fl / (PEAK_BF16_TFLOPS * 1e12)
+                roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                            "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                            "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": round(by / d["calls"]), "algorithmic_flops_per_launch": round(fl / d["calls"]),
+                            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                            "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
                             "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                             "share_of_kernel_time": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3)}
                 break

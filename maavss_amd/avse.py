@@ -102,6 +102,27 @@ class _AVSEFunction(torch.autograd.Function):
         return (None, None, None) + tuple(grads.get(n) for n in names)
 
 
+class _AEFunction(torch.autograd.Function):
+    """audio_ae_forward (avse_model_final.py:254-256): stft_encoder -> stft_decoder as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, model, x_a, *params):
+        out, saved = model._ae_forward(x_a, train=model.training)
+        ctx.model, ctx.saved, ctx.was_training = model, saved, model.training
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model = ctx.model
+        if not ctx.was_training:
+            raise _lib.MaavssError("backward through an eval-mode forward (running-statistics BatchNorm) is not built; "
+                                   "call model.train() for training steps")
+        grads = model._ae_backward(ctx.saved, d_out.contiguous().float())
+        ctx.saved = None
+        return (None, None) + tuple(grads.get(n) if ctx.needs_input_grad[2 + i] else None
+                                    for i, n in enumerate(model._ae_param_names))
+
+
 class AV_Fusion_Model_Frames(nn.Module):
     def __init__(self, stft_shape, frame_shape, hops_per_frame, latent_channels=16, fc_size=4096, *,
                  spatial_match="exact", precise=False):
@@ -154,9 +175,10 @@ class AV_Fusion_Model_Frames(nn.Module):
         self.fc2 = nn.Linear(flat // 2, FUSED_DIM, bias=False)
 
         mods = []
+        self._dec_plan = []
         if self._enc_pool is None:
-            for (ci, co, k, st, op, bn) in stft_decoder_plan(self.t_a, self.n_bins, self.t_v, self.s_v,
-                                                             latent_channels, stft_shape[1]):
+            self._dec_plan = stft_decoder_plan(self.t_a, self.n_bins, self.t_v, self.s_v, latent_channels, stft_shape[1])
+            for (ci, co, k, st, op, bn) in self._dec_plan:
                 mods.append(nn.ConvTranspose2d(ci, co, k, st, (1, 4), op, bias=False))
                 if bn:
                     mods += [nn.BatchNorm2d(co), nn.Tanh()]
@@ -169,6 +191,9 @@ class AV_Fusion_Model_Frames(nn.Module):
         # parameters that take part in forward(), in a fixed order (stft_decoder.* get no gradient, like the reference)
         self._param_names = [n for n, _ in self.named_parameters()
                              if not n.startswith("stft_decoder.") and not n.startswith("stft_autoencoder.")]
+        # parameters of audio_ae_forward (named_parameters lists shared modules once, under their first name)
+        self._ae_param_names = [n for n, _ in self.named_parameters()
+                                if n.startswith("stft_encoder.") or n.startswith("stft_decoder.")]
 
     # ---- reference API: gradient toggles (avse_model_final.py:216-232) --------------------------------
     def toggle_fusion_grads(self, toggle):
@@ -186,8 +211,13 @@ class AV_Fusion_Model_Frames(nn.Module):
             m.requires_grad_(toggle)
 
     def audio_ae_forward(self, x_a):
-        raise NotImplementedError("stft_autoencoder (ConvTranspose2d decoder) is outside the training hot path of "
-                                  "forward(); scheduled as SURVEY.md 8(f) row f2")
+        """stft_autoencoder(x_a): [B,2,T_a,F] -> [B,2,T_a,F] (avse_model_final.py:254-256; train_audio_net.py:108)."""
+        if self._enc_pool is not None:
+            raise NotImplementedError("the STFT autoencoder is only defined for the reference's exact shape matching "
+                                      "(spatial_match='exact'): the 'adaptive' extension has no decoder")
+        _lib.require_cuda(x_a)
+        pd = dict(self.named_parameters())
+        return _AEFunction.apply(self, x_a, *[pd[n] for n in self._ae_param_names])
 
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, x_a, x_v):
@@ -205,6 +235,113 @@ class AV_Fusion_Model_Frames(nn.Module):
 
     def _aud(self, i):
         return self.stft_encoder[3 * i], self.stft_encoder[3 * i + 1]
+
+    # ---- STFT autoencoder engine (K10 + K11) ---------------------------------------------------------------
+    def _dec(self, j):
+        """(ConvTranspose2d, BatchNorm2d or None) of decoder layer j."""
+        idx = 3 * j
+        has_bn = self._dec_plan[j][5]
+        return self.stft_decoder[idx], (self.stft_decoder[idx + 1] if has_bn else None)
+
+    @staticmethod
+    def _pad_c(t, dim, c):
+        """zero-pad dimension `dim` of t to c entries (BatchNorm kernels take C = power of two >= 4: a 2-channel layer
+        runs with two dead channels, which stay exactly zero through BN (beta 0), tanh and the backward pass)."""
+        if t.shape[dim] == c:
+            return t.contiguous()
+        shp = list(t.shape)
+        shp[dim] = c - t.shape[dim]
+        return torch.cat((t, torch.zeros(shp, device=t.device, dtype=t.dtype)), dim=dim).contiguous()
+
+    def _bn2d_stats(self, y, bn, c_real, count, train):
+        """(mean, invstd) of a channels-last map whose last c - c_real channels are zero padding."""
+        c = y.shape[-1]
+        if c == c_real:
+            rm, rv = bn.running_mean, bn.running_var
+        else:
+            rm = self._pad_c(bn.running_mean, 0, c)
+            rv = torch.cat((bn.running_var, torch.ones(c - c_real, device=y.device, dtype=torch.float32)))
+        if not train:
+            return ops.bn_eval_stats(rm, rv, bn.eps)
+        mean, invstd = ops.bn_finalize(ops.bn_stats(y, c), count, rm, rv, bn.num_batches_tracked, bn.eps, bn.momentum)
+        if c != c_real:
+            bn.running_mean.copy_(rm[:c_real])
+            bn.running_var.copy_(rv[:c_real])
+        return mean, invstd
+
+    def _ae_forward(self, x_a, train=True):
+        b = x_a.shape[0]
+        assert tuple(x_a.shape[1:]) == (2, self.t_a, self.n_bins)
+        x_a = x_a.contiguous().float()
+        sv = {"enc": [], "dec": []}
+        cur, nchw = x_a, True
+        for i, (ci, co, st, pw) in enumerate(self._enc_plan):
+            conv, bn = self._aud(i)
+            y = ops.conv2d_fwd(cur, conv.weight.detach(), st, pw, nchw)
+            ho, wo = y.shape[1], y.shape[2]
+            mean, invstd = self._bn2d_stats(y, bn, co, b * ho * wo, train)
+            y5 = y.view(b, 1, ho, wo, co)
+            out, _ = ops.bn_pool_act_fwd(y5, mean, invstd, bn.weight.detach(), bn.bias.detach(), 1, ops.BN_TANH)
+            sv["enc"].append(dict(x=cur, nchw=nchw, y=y5, mean=mean, invstd=invstd, out=out, hw=(ho, wo)))
+            cur, nchw = out.view(b, ho, wo, co), False
+        for j, (ci, co, k, st, op, has_bn) in enumerate(self._dec_plan):
+            convt, bn = self._dec(j)
+            ci_p = cur.shape[-1]
+            co_p = max(co, 4) if has_bn else co
+            w = self._pad_c(self._pad_c(convt.weight.detach(), 0, ci_p), 1, co_p)
+            y = ops.convt2d_fwd(cur, w, st, op, out_nhwc=has_bn)
+            rec = dict(x=cur, w=w, hw_in=(cur.shape[1], cur.shape[2]))
+            if has_bn:
+                ho, wo = y.shape[1], y.shape[2]
+                mean, invstd = self._bn2d_stats(y, bn, co, b * ho * wo, train)
+                gamma, beta = self._pad_c(bn.weight.detach(), 0, co_p), self._pad_c(bn.bias.detach(), 0, co_p)
+                y5 = y.view(b, 1, ho, wo, co_p)
+                out, _ = ops.bn_pool_act_fwd(y5, mean, invstd, gamma, beta, 1, ops.BN_TANH)
+                rec.update(y=y5, mean=mean, invstd=invstd, gamma=gamma, out=out, hw=(ho, wo))
+                cur = out.view(b, ho, wo, co_p)
+            else:
+                cur = y
+            sv["dec"].append(rec)
+        return cur, sv
+
+    def _ae_backward(self, sv, d_out):
+        grads = {}
+        b = d_out.shape[0]
+        dcur = d_out                                    # NCHW gradient of the last (BN-less) layer's output
+        for j in reversed(range(len(self._dec_plan))):
+            ci, co, k, st, op, has_bn = self._dec_plan[j]
+            s = sv["dec"][j]
+            idx = 3 * j
+            if has_bn:
+                ho, wo = s["hw"]
+                co_p = s["gamma"].shape[0]
+                gw = torch.empty(co_p, device=d_out.device, dtype=torch.float32)
+                gb = torch.empty(co_p, device=d_out.device, dtype=torch.float32)
+                dy = ops.bn_pool_act_bwd(dcur.view(b, 1, ho, wo, co_p), s["out"], None, s["y"], s["mean"], s["invstd"], s["gamma"], 1,
+                                         ops.BN_TANH, dgamma=gw, dbeta=gb).view(b, ho, wo, co_p)
+                grads[f"stft_decoder.{idx + 1}.weight"] = gw[:co].clone()
+                grads[f"stft_decoder.{idx + 1}.bias"] = gb[:co].clone()
+            else:
+                dy = dcur
+            dw = ops.convt2d_wgrad(s["x"], dy, s["w"].shape, st, op, out_nhwc=has_bn)
+            grads[f"stft_decoder.{idx}.weight"] = dw[:ci, :co].contiguous()
+            dcur = ops.convt2d_dgrad(dy, s["w"], s["hw_in"], st, op, out_nhwc=has_bn)
+        n_layers = len(self._enc_plan)
+        for i in reversed(range(n_layers)):
+            ci, co, st, pw = self._enc_plan[i]
+            conv, bn = self._aud(i)
+            s = sv["enc"][i]
+            ho, wo = s["hw"]
+            gw = torch.empty(co, device=d_out.device, dtype=torch.float32)
+            gb = torch.empty(co, device=d_out.device, dtype=torch.float32)
+            dy = ops.bn_pool_act_bwd(dcur.view(b, 1, ho, wo, co), s["out"], None, s["y"], s["mean"], s["invstd"], bn.weight.detach(), 1,
+                                     ops.BN_TANH, dgamma=gw, dbeta=gb).view(b, ho, wo, co)
+            grads[f"stft_encoder.{3 * i + 1}.weight"], grads[f"stft_encoder.{3 * i + 1}.bias"] = gw, gb
+            grads[f"stft_encoder.{3 * i}.weight"] = ops.conv2d_wgrad(s["x"], dy, conv.weight.shape, st, pw, s["nchw"])
+            if i > 0:
+                hin, win = sv["enc"][i - 1]["hw"]
+                dcur = ops.conv2d_dgrad(dy, conv.weight.detach(), (hin, win), st, pw)
+        return grads
 
     def _engine_forward(self, x_a, x_v, train=True):
         # train=False (model.eval()): BatchNorm uses its running statistics and leaves them untouched (forward only)

@@ -237,6 +237,46 @@ def conv2d_wgrad(x, dy, w_shape, stride, pw, in_nchw, dw=None, beta=0):
     return dw
 
 
+# ---------------------------------------------------------------------------------------------- convt2d (STFT decoder)
+def convt2d_out(h, w, kw, stride, opad):
+    return (h - 1) * stride[0] + 1 + opad[0], (w - 1) * stride[1] - 8 + kw + opad[1]
+
+
+def convt2d_fwd(x, w, stride, opad, out_nhwc):
+    """x NHWC [B,Hi,Wi,Ci], w [Ci,Co,3,kw] -> y NHWC [B,Ho,Wo,Co] or NCHW [B,Co,Ho,Wo] (last decoder layer)."""
+    _f32(x, w)
+    b, hi, wi, ci = x.shape
+    assert w.shape[0] == ci and w.shape[2] == 3
+    co, kw = w.shape[1], w.shape[3]
+    ho, wo = convt2d_out(hi, wi, kw, stride, opad)
+    y = torch.empty((b, ho, wo, co) if out_nhwc else (b, co, ho, wo), device=x.device, dtype=torch.float32)
+    call("maavss_convt2d_fwd", ptr(x), ptr(w), ptr(y), b, ci, hi, wi, co, kw, stride[0], stride[1], opad[0], opad[1],
+         1 if out_nhwc else 0, stream_ptr())
+    return y
+
+
+def convt2d_dgrad(dy, w, in_hw, stride, opad, out_nhwc):
+    _f32(dy, w)
+    ci, co, kw = w.shape[0], w.shape[1], w.shape[3]
+    b = dy.shape[0]
+    dx = torch.empty(b, in_hw[0], in_hw[1], ci, device=dy.device, dtype=torch.float32)
+    call("maavss_convt2d_dgrad", ptr(dy), ptr(w), ptr(dx), b, ci, in_hw[0], in_hw[1], co, kw, stride[0], stride[1], opad[0],
+         opad[1], 1 if out_nhwc else 0, stream_ptr())
+    return dx
+
+
+def convt2d_wgrad(x, dy, w_shape, stride, opad, out_nhwc):
+    _f32(x, dy)
+    b, hi, wi, ci = x.shape
+    co, kw = w_shape[1], w_shape[3]
+    nchunk = query("maavss_convt2d_wgrad_nchunk", b, hi, wi)
+    ws = torch.empty(nchunk * ci * co * 3 * kw, device=x.device, dtype=torch.float32)
+    dw = torch.empty(ci, co, 3, kw, device=x.device, dtype=torch.float32)
+    call("maavss_convt2d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, ci, hi, wi, co, kw, stride[0], stride[1], opad[0],
+         opad[1], 1 if out_nhwc else 0, 0, stream_ptr())
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------- lstm
 def lstm_fwd(gx, whh_f, whh_b):
     """gx [B,L,2,4,256] -> av [B,L,512] and the saved state (hp, gs, cs)."""

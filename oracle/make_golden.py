@@ -11,7 +11,8 @@ stores the results as small fixtures.  It also asserts that the oracle twin
 pins the oracle.  Nothing of the reference (source or bytecode) is written out:
 only numbers.
 
-    python oracle/make_golden.py            # writes tests/golden/avse_{P,S,L}.npz
+    python oracle/make_golden.py            # writes tests/golden/avse_{P,S,L}.npz and avse_ae_{P,S}.npz
+    python oracle/make_golden.py ae         # only the autoencoder fixtures (audio_ae_forward)
 """
 import contextlib
 import io
@@ -112,7 +113,46 @@ def run(model, x_a, x_v, y_a, y_v):
     return out
 
 
+def run_ae(model, y_stft):
+    """One step of the reference's autoencoder trainer (train_audio_net.py:97-110): yh = audio_ae_forward(y),
+    loss = mse(yh, y), backward.  Full output, loss, every gradient's norm + 8 samples, decoder/encoder BN statistics."""
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    yh = model.audio_ae_forward(y_stft)
+    loss = torch.nn.functional.mse_loss(yh, y_stft)
+    loss.backward()
+    out = {"yh_sample": yh.detach().flatten()[::61].numpy(), "yh_sum": np.float64(yh.detach().double().sum().item()),
+           "yh_abs_sum": np.float64(yh.detach().double().abs().sum().item()), "loss": np.float64(loss.item())}
+    names, gnorm, gsample = [], [], []
+    for k, p in model.named_parameters():
+        if not (k.startswith("stft_encoder.") or k.startswith("stft_decoder.")):
+            continue
+        names.append(k)
+        g = p.grad.detach().flatten()
+        gnorm.append(g.double().norm().item())
+        idx = (torch.arange(8, dtype=torch.long) * (g.numel() - 1)) // 7
+        gsample.append(g[idx].numpy())
+    out["param_names"] = np.array(names)
+    out["grad_norm"] = np.array(gnorm)
+    out["grad_sample"] = np.stack(gsample)
+    bn_names, bn_mean, bn_var = [], [], []
+    for k, b in model.named_buffers():
+        if not (k.startswith("stft_encoder.") or k.startswith("stft_decoder.")):
+            continue
+        if k.endswith("running_mean"):
+            bn_names.append(k[:-len(".running_mean")])
+            bn_mean.append(b.double().sum().item())
+        if k.endswith("running_var"):
+            bn_var.append(b.double().sum().item())
+    out["bn_names"] = np.array(bn_names)
+    out["bn_running_mean_sum"] = np.array(bn_mean)
+    out["bn_running_var_sum"] = np.array(bn_var)
+    return out
+
+
 def main():
+    only_ae = len(sys.argv) > 1 and sys.argv[1] == "ae"
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     torch.set_num_threads(8)
     with reference_on_cpu():
@@ -133,6 +173,24 @@ def main():
             ref.load_state_dict(orc.seeded_state_dict(twin, SEED), strict=True)
             orc.load_seeded(twin, SEED)
             batch = orc.synthetic_batch(b, t, w, t_a, n_bins, hpf, SEED + 1)
+            meta = dict(batch=b, frames=t, width=w, fft_len=fft, hops_per_frame=hpf, seed=SEED,
+                        lr=LR, loss_coeff=LOSS_COEFF)
+            if name in ("P", "S"):
+                # autoencoder step first (fresh BN buffers); the weights are re-seeded before the fusion step below
+                y_stft = batch[0]          # the synthetic STFT [B,2,T_a,F] (the trainer feeds the clean STFT to the autoencoder)
+                ae_ref, ae_twin = run_ae(ref, y_stft), run_ae(twin, y_stft)
+                for k in ae_ref:
+                    if ae_ref[k].dtype.kind in "US":
+                        assert (ae_ref[k] == ae_twin[k]).all(), k
+                    else:
+                        np.testing.assert_allclose(ae_twin[k], ae_ref[k], rtol=2e-5, atol=1e-6, err_msg=f"ae {name}:{k}")
+                np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"avse_ae_{name}.npz"),
+                                    **ae_ref, **{f"meta_{k}": np.array(v) for k, v in meta.items()})
+                print(f"[golden] ae {name}: loss={ae_ref['loss']:.8f} oracle==reference OK", flush=True)
+                ref.load_state_dict(orc.seeded_state_dict(twin, SEED), strict=True)
+                orc.load_seeded(twin, SEED)
+            if only_ae:
+                continue
             got_ref = run(ref, *batch)
             got_twin = run(twin, *batch)
             for k in got_ref:
@@ -140,8 +198,6 @@ def main():
                     assert (got_ref[k] == got_twin[k]).all(), k
                 else:
                     np.testing.assert_allclose(got_twin[k], got_ref[k], rtol=2e-5, atol=1e-6, err_msg=f"{name}:{k}")
-            meta = dict(batch=b, frames=t, width=w, fft_len=fft, hops_per_frame=hpf, seed=SEED,
-                        lr=LR, loss_coeff=LOSS_COEFF)
             np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"avse_{name}.npz"),
                                 **got_ref, **{f"meta_{k}": np.array(v) for k, v in meta.items()})
             print(f"[golden] {name}: loss={got_ref['loss']:.8f} params={len(got_ref['param_names'])} "

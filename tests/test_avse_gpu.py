@@ -166,6 +166,54 @@ def test_eval_mode_uses_running_statistics():
         assert torch.equal(b, before[k]), k
 
 
+@pytest.mark.parametrize("name", ["S", "P"])
+def test_audio_autoencoder_matches_reference_golden(golden_dir, name):
+    """audio_ae_forward through the HIP engine (conv2d / convt2d / BN kernels) vs the reference's own numbers:
+    output, loss, every encoder and decoder gradient, BN running statistics (train_audio_net.py:107-109)."""
+    from oracle import avse_ref_cpu as orc
+    z = np.load(os.path.join(golden_dir, f"avse_ae_{name}.npz"), allow_pickle=False)
+    m = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+    model, _, (x_a, _, _, _) = _build(m, precise=True)
+    model.train()
+    y = x_a.cuda()
+    yh = model.audio_ae_forward(y)
+    assert yh.shape == y.shape
+    loss = torch.nn.functional.mse_loss(yh, y)
+    loss.backward()
+    np.testing.assert_allclose(yh.detach().flatten()[::61].cpu().numpy(), z["yh_sample"], rtol=0, atol=2e-5)
+    assert abs(yh.detach().double().sum().item() - z["yh_sum"]) <= 1e-5 * z["yh_abs_sum"] + 1e-4
+    assert abs(loss.item() - z["loss"]) < 2e-6
+    params = dict(model.named_parameters())
+    for i, k in enumerate(z["param_names"]):
+        g = params[str(k)].grad
+        gn = g.double().norm().item()
+        assert abs(gn - z["grad_norm"][i]) <= 2e-3 * z["grad_norm"][i] + 1e-7, (str(k), gn, z["grad_norm"][i])
+        flat = g.flatten()
+        idx = (torch.arange(8) * (flat.numel() - 1)) // 7
+        scale = z["grad_norm"][i] / np.sqrt(flat.numel())
+        np.testing.assert_allclose(flat[idx.cuda()].cpu().numpy(), z["grad_sample"][i], rtol=5e-3, atol=5e-2 * scale, err_msg=str(k))
+    bufs = dict(model.named_buffers())
+    for i, k in enumerate(z["bn_names"]):
+        k = str(k)
+        assert abs(bufs[k + ".running_mean"].double().sum().item() - z["bn_running_mean_sum"][i]) < 1e-4, k
+        assert abs(bufs[k + ".running_var"].double().sum().item() - z["bn_running_var_sum"][i]) < 1e-3, k
+    # forward() gives the decoder no gradient (reference behaviour) and still works after an autoencoder step
+    assert all(params[n].grad is not None for n in params if n.startswith("stft_decoder."))
+
+
+def test_audio_autoencoder_eval_mode_matches_oracle():
+    from oracle import avse_ref_cpu as orc
+    m = dict(batch=2, frames=8, width=128, fft_len=256, hops_per_frame=8, seed=21)
+    model, twin, (x_a, _, _, _) = _build(m, precise=True)
+    orc.load_seeded(twin, m["seed"])
+    twin.eval()
+    model.eval()
+    with torch.no_grad():
+        ref = twin.audio_ae_forward(x_a)
+        got = model.audio_ae_forward(x_a.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=3e-5)
+
+
 def test_reference_constructor_guards():
     import maavss_amd
     with pytest.raises(ValueError):

@@ -266,3 +266,31 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_step(pc, g.cuda(), m, v, 1e-3, step)
     close(pc, p.detach(), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("ci,co,kw,stride,opad,nhwc", [(16, 8, 9, (2, 2), (1, 1), True), (4, 4, 9, (2, 2), (1, 1), True),
+                                                     (4, 2, 10, (1, 2), (0, 1), False), (8, 4, 9, (2, 1), (1, 0), True)])
+def test_convt2d_fwd_dgrad_wgrad_vs_torch(ci, co, kw, stride, opad, nhwc):
+    """K11: ConvTranspose2d(k=(3,kw), padding (1,4)) forward / input gradient / weight gradient vs torch on the CPU."""
+    import torch.nn.functional as F
+    from maavss_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, hi, wi = 2, 9, 17
+    x = torch.randn(b, ci, hi, wi, generator=g)
+    w = torch.randn(ci, co, 3, kw, generator=g) * 0.2
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv_transpose2d(x, w, stride=stride, padding=(1, 4), output_padding=opad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    wc = w.detach().cuda()
+    got = ops.convt2d_fwd(x_nhwc, wc, stride, opad, out_nhwc=nhwc)
+    got_nchw = got.permute(0, 3, 1, 2) if nhwc else got
+    assert tuple(got_nchw.shape) == tuple(y.shape)
+    np.testing.assert_allclose(got_nchw.cpu().numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    dyc = (dy.permute(0, 2, 3, 1) if nhwc else dy).contiguous().cuda()
+    dx = ops.convt2d_dgrad(dyc, wc, (hi, wi), stride, opad, out_nhwc=nhwc)
+    np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=2e-5)
+    dw = ops.convt2d_wgrad(x_nhwc, dyc, w.shape, stride, opad, out_nhwc=nhwc)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)

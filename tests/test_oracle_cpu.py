@@ -43,6 +43,29 @@ def test_avse_oracle_matches_reference_golden(golden_dir, name):
             assert abs(g.double().norm().item() - z["grad_norm"][i]) <= 1e-4 * z["grad_norm"][i] + 1e-9, k
 
 
+@pytest.mark.parametrize("name", ["S", "P"])
+def test_autoencoder_oracle_matches_reference_golden(golden_dir, name):
+    """audio_ae_forward (stft_encoder -> ConvTranspose2d decoder) + mse + backward, as train_audio_net.py:107-109."""
+    z = np.load(os.path.join(golden_dir, f"avse_ae_{name}.npz"), allow_pickle=False)
+    m = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+    n_bins, t_a = m["fft_len"] // 2 + 1, m["hops_per_frame"] * m["frames"]
+    model = orc.AVFusionFramesRef([m["batch"], 2, t_a, n_bins], [m["batch"], 1, m["frames"], m["width"], m["width"]],
+                                  m["hops_per_frame"])
+    orc.load_seeded(model, m["seed"])
+    model.train()
+    y = orc.synthetic_batch(m["batch"], m["frames"], m["width"], t_a, n_bins, m["hops_per_frame"], m["seed"] + 1)[0]
+    yh = model.audio_ae_forward(y)
+    assert yh.shape == y.shape
+    loss = torch.nn.functional.mse_loss(yh, y)
+    loss.backward()
+    np.testing.assert_allclose(yh.detach().flatten()[::61].numpy(), z["yh_sample"], rtol=1e-4, atol=2e-6)
+    assert abs(loss.item() - z["loss"]) < 1e-6
+    params = dict(model.named_parameters())
+    for i, k in enumerate(z["param_names"]):
+        gn = params[str(k)].grad.double().norm().item()
+        assert abs(gn - z["grad_norm"][i]) <= 1e-4 * z["grad_norm"][i] + 1e-9, k
+
+
 def test_constructor_shapes_and_guards():
     with pytest.raises(ValueError):
         orc.AVFusionFramesRef([1, 2, 128, 257], [1, 1, 16, 224, 224], 8)      # reference would loop forever
