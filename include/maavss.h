@@ -44,6 +44,13 @@ int maavss_stft_fwd(const float* audio, int64_t batch, int64_t length, int64_t a
 int maavss_stft_normalise(float* y, float* x, const float* noise, const float* clip_absmax, int64_t batch,
                           int n_frames, int n_bins_out, float sigma, uint64_t seed, void* stream);
 
+/* inverse: AV_Dataset.istft (av_dataset.py:181-201) = torch.istft(n_fft, hop, win_length = n_fft, window, normalized,
+ * onesided, center).  spec [batch][2][n_frames][n_bins_in] (n_bins_in = n_fft/2+1, or n_fft/2 when the Nyquist bin was
+ * trimmed: read as zero), window [n_fft] = the RAW periodic Hamming window; frames_ws [batch][n_frames][n_fft] scratch;
+ * audio [batch][audio_stride], hop*(n_frames-1) valid samples per clip. */
+int maavss_istft(const float* spec, int64_t batch, int n_frames, int n_bins_in, const float* window, int n_fft, int hop,
+                 int normalized, float* frames_ws, float* audio, int64_t audio_stride, void* stream);
+
 /* ---- generic f32 GEMM on MFMA -----------------------------------------------------------------
  * C[M,N] = act(alpha * op(A)[M,K] . op(B)[N,K]^T) (+ C when beta = 1).  Replaces the nn.Linear forwards
  * of avse_model_final.py:141-146,203-213,244-249,264-268, the LSTM input projection (:132,242) and the

@@ -145,3 +145,110 @@ extern "C" int maavss_stft_normalise(float* y, float* x, const float* noise, con
   MAAVSS_LAUNCH_CHECK("stft_normalise_kernel");
   return MAAVSS_OK;
 }
+
+// ---- inverse STFT (AV_Dataset.istft, av_dataset.py:181-201: torch.istft(n_fft, hop, win_length = n_fft, window,
+// normalized, onesided, center)) -- the audio side of SURVEY.md 8 row f2 (mask / autoencoder output -> waveform).
+// Pass 1, one wavefront per frame: the one-sided bins of the [B,2,T,F] tensor are mirrored into the Hermitian
+// spectrum in LDS (imaginary parts of DC and Nyquist dropped as irfft does; a trimmed Nyquist bin reads as zero, the
+// reference pads it), the same Stockham FFT runs with conjugated twiddles, and the real part, scaled by
+// (normalized ? sqrt(N) : 1) / N and multiplied by the synthesis window, goes to frames[B][T][N].
+// Pass 2, one thread per output sample: overlap-add of the <= ceil(N / hop) frames that cover it, divided by the
+// window-square envelope, with the N/2 samples of centre padding cut off (length hop * (T - 1)).
+template <int NFFT, int FPB>
+__global__ __launch_bounds__(64 * FPB) void istft_frames_kernel(const float* __restrict__ spec, const float* __restrict__ window,
+                                                                int n_frames, int n_bins_in, int total_frames, float scale,
+                                                                float* __restrict__ frames) {
+  constexpr int LOG2N = NFFT == 256 ? 8 : (NFFT == 512 ? 9 : 10);
+  __shared__ float2 buf[2][FPB][NFFT];
+  __shared__ float2 tw[NFFT / 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int q = threadIdx.x; q < NFFT / 2; q += blockDim.x) {
+    float s, c;
+    sincospif(2.0f * (float)q / (float)NFFT, &s, &c);   // conjugate twiddles: inverse transform
+    tw[q] = make_float2(c, s);
+  }
+  const int fid = blockIdx.x * FPB + wv;
+  const bool active = fid < total_frames;
+  const int b = active ? fid / n_frames : 0, t = active ? fid % n_frames : 0;
+  const int64_t plane = (int64_t)n_frames * n_bins_in;
+  const float* re = spec + ((int64_t)b * 2) * plane + (int64_t)t * n_bins_in;
+  const float* im = re + plane;
+  for (int k = lane; k <= NFFT / 2; k += 64) {
+    float2 v = make_float2(0.f, 0.f);
+    if (active && k < n_bins_in) v = make_float2(re[k], (k == 0 || k == NFFT / 2) ? 0.f : im[k]);
+    buf[0][wv][k] = v;
+    if (k > 0 && k < NFFT / 2) buf[0][wv][NFFT - k] = make_float2(v.x, -v.y);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < LOG2N; ++s) {
+    const int p = 1 << s;
+    for (int i = lane; i < NFFT / 2; i += 64) {
+      const int k = i & (p - 1);
+      float2 u0 = buf[cur][wv][i];
+      float2 u1 = buf[cur][wv][i + NFFT / 2];
+      float2 w = tw[k * (NFFT / (2 * p))];
+      float2 v = make_float2(u1.x * w.x - u1.y * w.y, u1.x * w.y + u1.y * w.x);
+      const int j = ((i - k) << 1) + k;
+      buf[cur ^ 1][wv][j] = make_float2(u0.x + v.x, u0.y + v.y);
+      buf[cur ^ 1][wv][j + p] = make_float2(u0.x - v.x, u0.y - v.y);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (!active) return;
+  float* out = frames + (int64_t)fid * NFFT;
+  for (int n = lane; n < NFFT; n += 64) out[n] = buf[cur][wv][n].x * scale * window[n];
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                                        int n_fft, int hop, int n_frames, int out_len, int64_t out_stride,
+                                                        int64_t total, float* __restrict__ audio) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / out_len), n = (int)(i % out_len);
+    const int pos = n + n_fft / 2;                       // position in the centre-padded signal
+    int t_hi = pos / hop;
+    if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+    int t_lo = (pos - n_fft + hop) / hop;                // smallest t with t*hop + n_fft > pos
+    if (pos - n_fft + 1 <= 0) t_lo = 0;
+    float num = 0.f, den = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int j = pos - t * hop;
+      if (j < 0 || j >= n_fft) continue;
+      num += frames[((int64_t)b * n_frames + t) * n_fft + j];
+      den += window[j] * window[j];
+    }
+    audio[(int64_t)b * out_stride + n] = num / den;
+  }
+}
+
+extern "C" int maavss_istft(const float* spec, int64_t batch, int n_frames, int n_bins_in, const float* window, int n_fft,
+                            int hop, int normalized, float* frames_ws, float* audio, int64_t audio_stride, void* stream) {
+  MAAVSS_CHECK_ARG(n_fft == 256 || n_fft == 512 || n_fft == 1024, "istft: n_fft must be 256, 512 or 1024 (got %d)", n_fft);
+  MAAVSS_CHECK_ARG(spec && window && frames_ws && audio, "istft: null pointer");
+  MAAVSS_CHECK_ARG(batch > 0 && hop > 0 && n_frames > 1, "istft: needs at least two frames");
+  MAAVSS_CHECK_ARG(n_bins_in == n_fft / 2 || n_bins_in == n_fft / 2 + 1, "istft: n_bins must be n_fft/2 (trimmed) or n_fft/2+1");
+  MAAVSS_CHECK_ARG(hop <= n_fft, "istft: hop larger than the window leaves gaps (window envelope would be zero)");
+  const int out_len = hop * (n_frames - 1);
+  MAAVSS_CHECK_ARG(audio_stride >= out_len, "istft: audio_stride smaller than hop*(n_frames-1)");
+  MAAVSS_CHECK_ARG((int64_t)(n_frames - 1) * hop + n_fft >= out_len + n_fft / 2, "istft: frames do not cover the output");
+  const int total = (int)(batch * n_frames);
+  const float scale = (normalized ? sqrtf((float)n_fft) : 1.f) / (float)n_fft;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N, FPB)                                                                                                   \
+  hipLaunchKernelGGL((istft_frames_kernel<N, FPB>), dim3(cdiv(total, FPB)), dim3(64 * FPB), 0, st, spec, window, n_frames, \
+                     n_bins_in, total, scale, frames_ws)
+  if (n_fft == 256) LAUNCH(256, 4);
+  else if (n_fft == 512) LAUNCH(512, 4);
+  else LAUNCH(1024, 2);
+#undef LAUNCH
+  MAAVSS_LAUNCH_CHECK("istft_frames_kernel");
+  const int64_t n_out = batch * out_len;
+  int grid = cdiv(n_out, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(grid), dim3(256), 0, st, frames_ws, window, n_fft, hop, n_frames, out_len, audio_stride,
+                     n_out, audio);
+  MAAVSS_LAUNCH_CHECK("istft_ola_kernel");
+  return MAAVSS_OK;
+}

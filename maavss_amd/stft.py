@@ -27,6 +27,8 @@ class STFT:
         self.normalize_output_fft = normalize_output_fft
         k = torch.arange(fft_len, dtype=torch.float64)
         w = 0.54 - 0.46 * torch.cos(2 * math.pi * k / fft_len)        # torch.hamming_window (periodic)
+        self.normalized = normalized
+        self.raw_window = w.float().to(device)                         # synthesis window of inverse()
         if normalized:
             w = w / w.pow(2).sum().sqrt()
         self.window = w.float().to(device)
@@ -54,3 +56,19 @@ class STFT:
             _lib.call("maavss_stft_normalise", _lib.ptr(y), _lib.ptr(x), _lib.ptr(noise), _lib.ptr(amax), b,
                       n_frames, f, float(self.noise_std), int(seed), st)
         return x, y
+
+    def inverse(self, stft):
+        """AV_Dataset.istft (av_dataset.py:181-201): [2, T_a, F] or [B, 2, T_a, F] (cuda) -> audio [hop*(T_a-1)] /
+        [B, hop*(T_a-1)].  As in the reference, the Nyquist bin trimmed by `trim_stft_end` is padded back with zeros and
+        the scaling is torch.istft's `normalized` (frame_length ** 0.5), not the window-energy one the forward applies."""
+        _lib.require_cuda(stft)
+        single = stft.dim() == 3
+        spec = (stft.unsqueeze(0) if single else stft).contiguous().float()
+        b, two, n_frames, f = spec.shape
+        assert two == 2 and f == self.n_bins(), f"expected [.., 2, T, {self.n_bins()}], got {tuple(stft.shape)}"
+        out_len = self.hop * (n_frames - 1)
+        frames = torch.empty(b, n_frames, self.fft_len, device=spec.device, dtype=torch.float32)
+        audio = torch.empty(b, out_len, device=spec.device, dtype=torch.float32)
+        _lib.call("maavss_istft", _lib.ptr(spec), b, n_frames, f, _lib.ptr(self.raw_window), self.fft_len, self.hop,
+                  1 if self.normalized else 0, _lib.ptr(frames), _lib.ptr(audio), audio.stride(0), _lib.stream_ptr())
+        return audio[0] if single else audio

@@ -85,3 +85,14 @@ def synthetic_audio(batch, length, seed, sr=16000):
         ph = torch.rand(batch, 1, generator=g) * 2 * math.pi
         a = a + 0.2 * torch.sin(2 * math.pi * f * t[None, :] + ph)
     return a.clamp(-1, 1)
+
+
+def istft_ref(stft, fft_len, hop, normalized=True, trim_stft_end=False):
+    """AV_Dataset.istft (av_dataset.py:181-201), batched: stft [B,2,T_a,F] -> audio [B, hop*(T_a-1)].
+    The reference hands torch.istft the real view [F,T,2] (accepted by the torch of its day); the same function takes
+    the complex tensor today -- same arithmetic."""
+    if trim_stft_end:
+        stft = torch.nn.functional.pad(stft, (0, 1))
+    spec = torch.complex(stft[:, 0], stft[:, 1]).transpose(1, 2).contiguous()          # [B, F, T]
+    return torch.istft(spec, n_fft=fft_len, hop_length=hop, win_length=fft_len, window=hamming_periodic(fft_len),
+                       normalized=normalized, onesided=True)

@@ -93,6 +93,25 @@ def test_stft_oracle_vs_direct_dft(fft_len):
     np.testing.assert_allclose(w.numpy(), sref.hamming_periodic(fft_len).numpy(), atol=3e-7)
 
 
+def test_istft_oracle_vs_direct_overlap_add():
+    """istft_ref (torch.istft, what AV_Dataset.istft calls) against a float64 irfft + overlap-add written out by hand."""
+    fft_len, hop, frames = 256, 66, 20
+    g = torch.Generator().manual_seed(2)
+    spec = torch.randn(2, 2, frames, fft_len // 2 + 1, generator=g)
+    got = sref.istft_ref(spec, fft_len, hop, normalized=True)
+    w = sref.hamming_periodic(fft_len, torch.float64)
+    z = torch.complex(spec[:, 0].double(), spec[:, 1].double())                       # [B, T, F]
+    fr = torch.fft.irfft(z * fft_len ** 0.5, n=fft_len, dim=-1) * w                  # normalized: * sqrt(n_fft)
+    total = hop * (frames - 1) + fft_len
+    num = torch.zeros(2, total, dtype=torch.float64)
+    den = torch.zeros(total, dtype=torch.float64)
+    for t in range(frames):
+        num[:, t * hop:t * hop + fft_len] += fr[:, t]
+        den[t * hop:t * hop + fft_len] += w * w
+    want = (num / den)[:, fft_len // 2:fft_len // 2 + hop * (frames - 1)]
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+
+
 def test_vit_oracle_vs_hf_vit():
     """Independent cross-check of the restated ViT-S/8 against transformers.ViTModel (local config only)."""
     tr = pytest.importorskip("transformers")

@@ -53,3 +53,28 @@ def test_stft_device_noise_statistics():
     assert (x2 - x).abs().max().item() > 0.1      # different seed, different draw
     x3, _ = st(audio, seed=123)
     assert torch.equal(x3, x)                     # same seed, same draw
+
+
+@pytest.mark.parametrize("fft_len,hop,frames,trim,normalized", [(512, 66, 64, False, True), (256, 66, 64, False, True),
+                                                                (512, 66, 128, True, True), (1024, 100, 40, False, False)])
+def test_istft_matches_oracle(fft_len, hop, frames, trim, normalized):
+    """STFT.inverse == AV_Dataset.istft restated on torch.istft (av_dataset.py:181-201): random spectra (not the STFT
+    of anything, so the overlap-add / envelope arithmetic is exercised, not just a round trip) and a true round trip."""
+    import maavss_amd
+    from oracle import stft_ref_cpu as sref
+    g = torch.Generator().manual_seed(11)
+    f = fft_len // 2 + (0 if trim else 1)
+    spec = torch.randn(3, 2, frames, f, generator=g)
+    st = maavss_amd.STFT(fft_len, hop, normalized=normalized, trim_stft_end=trim)
+    got = st.inverse(spec.cuda())
+    want = sref.istft_ref(spec, fft_len, hop, normalized, trim)
+    assert got.shape == want.shape == (3, hop * (frames - 1))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+    one = st.inverse(spec[1].cuda())
+    np.testing.assert_allclose(one.cpu().numpy(), want[1].numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+    # round trip through the HIP forward: the reference's own scaling mismatch (window energy vs sqrt(n_fft)) is a constant
+    audio = sref.synthetic_audio(2, hop * frames, 4)
+    _, y = st(audio.cuda(), want_x=False)
+    back = st.inverse(y)
+    ref_back = sref.istft_ref(sref.stft_ref(audio, fft_len, hop, normalized, trim), fft_len, hop, normalized, trim)
+    np.testing.assert_allclose(back.cpu().numpy(), ref_back.numpy(), rtol=0, atol=3e-5 * float(ref_back.abs().max()))
