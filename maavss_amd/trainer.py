@@ -40,6 +40,7 @@ class FlatParams:
         fusion = [(n, p) for n, p in named if n.startswith(_FUSION_PREFIXES)]
         other = [(n, p) for n, p in named if not n.startswith(_FUSION_PREFIXES)]
         self.names, self.offsets, self.shapes = [], {}, {}
+        self.torch_order = [n for n, _ in named]     # index i of torch.optim.Adam(model.parameters()).state_dict()
         off = 0
         for n, p in fusion + other:
             self.names.append(n)
@@ -82,13 +83,50 @@ class FusedAdam:
         self.flat.grads.zero_()        # memset; the flat views stay attached to p.grad
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "lr": self.lr, "betas": self.betas, "eps": self.eps}
+        """torch.optim.Adam's layout (what utilities.save_checkpoint stores as 'optimizer_state_dict',
+        utilities.py:168-175): per-parameter step / exp_avg / exp_avg_sq keyed by the position of the parameter in
+        model.parameters(), plus one param_group."""
+        f = self.flat
+        state = {}
+        for i, n in enumerate(f.torch_order):
+            o, k = f.offsets[n], 1
+            for d in f.shapes[n]:
+                k *= d
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + k].view(f.shapes[n]).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(f.shapes[n]).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(f.torch_order)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts the dict above and a reference checkpoint's torch.optim.Adam state (parameters the reference never
+        stepped -- stft_decoder.* under forward() -- have no entry there: their moments stay zero)."""
+        f = self.flat
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(f.torch_order):
+            raise ValueError(f"optimizer state has {sum(len(g['params']) for g in groups)} parameters in {len(groups)} group(s); "
+                             f"this model has {len(f.torch_order)} in one")
+        self.lr = float(groups[0]["lr"])
+        self.betas = tuple(float(b) for b in groups[0]["betas"])
+        self.eps = float(groups[0]["eps"])
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, n in enumerate(f.torch_order):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            o, k = f.offsets[n], st["exp_avg"].numel()
+            if tuple(st["exp_avg"].shape) != f.shapes[n]:
+                raise ValueError(f"optimizer state of parameter {i} ({n}) has shape {tuple(st['exp_avg'].shape)}, expected {f.shapes[n]}")
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): one fused step counter cannot represent that")
+        self.step_count = steps.pop() if steps else 0
 
 
 class GradSync:
@@ -144,13 +182,42 @@ class TrainStep:
         self.need = {n: bool(p.requires_grad) for n, p in model.named_parameters()}
         self.losses = None
 
-    def __call__(self, x_a, x_v, y_a, y_v, optimizer_step=True):
+    def __call__(self, x_a, x_v, y_a, y_v, optimizer_step=True, accumulate=False, last=True):
+        """One window: forward, loss / num_seq, backward.  `accumulate` adds into the flat gradient buffer instead of
+        overwriting it; the gradient all-reduce and Adam run only when `last` (sliding_window_step drives both)."""
         m = self.model
         (a, v, fused), sv = m._engine_forward(x_a, x_v, train=True)
+        self.outputs = (a, v, fused)
         self.losses, d_a, d_v = ops.mse_pair(a, y_a.contiguous(), v, y_v.contiguous(), self.loss_coeff, self.num_seq)
-        m._engine_backward(sv, d_a, d_v, None, self.need, grads=self.flat.grad_views, accumulate=False,
-                           on_fusion_done=self.sync.start_fusion)
-        self.sync.finish()
-        if optimizer_step:
-            self.opt.step(grad_scale=1.0 / self.sync.world)
+        m._engine_backward(sv, d_a, d_v, None, self.need, grads=self.flat.grad_views, accumulate=accumulate,
+                           on_fusion_done=self.sync.start_fusion if last else None)
+        if last:
+            self.sync.finish()
+            if optimizer_step:
+                self.opt.step(grad_scale=1.0 / self.sync.world)
+        return self.losses
+
+    def sliding_window_step(self, x_stft, y_stft, x_attn, y_attn, num_frames, hops_per_frame, collect=False):
+        """The reference's optimizer step over `num_seq` overlapping windows (train_avse_frames.py:143-181):
+        window j takes frames [j, j + num_frames) of x_attn [B,1,T,H,W] and the matching STFT frames of x_stft
+        [B,2,T_a,F]; its targets are attention frame j + idx_mid of y_attn and STFT frames of the same video frame
+        of y_stft, idx_mid = (num_seq - 1) // 2 (:105).  Every window contributes loss / num_seq to the gradients
+        (accumulated in the flat buffer); ONE gradient all-reduce and ONE Adam step follow.  Returns the last
+        window's (a_loss, v_loss, loss) like the reference logs (:183-188) and, with `collect`, the stitched
+        outputs (output_stft [B,2,hpf*num_seq,F], output_attn [B,1,num_seq,H,W]) of its callback (:150-176)."""
+        hpf, ns = hops_per_frame, self.num_seq
+        mid = (ns - 1) // 2
+        assert x_attn.shape[2] >= num_frames + ns - 1 and x_stft.shape[2] >= hpf * (num_frames + ns - 1)
+        outs_a, outs_v = [], []
+        for j in range(ns):
+            xa = x_stft[:, :, hpf * j:hpf * (j + num_frames), :]
+            ya = y_stft[:, :, hpf * (j + mid):hpf * (j + mid + 1), :]
+            xv = x_attn[:, :, j:j + num_frames]
+            yv = y_attn[:, :, j + mid]
+            self(xa, xv, ya, yv, accumulate=j > 0, last=j == ns - 1)
+            if collect:
+                outs_a.append(self.outputs[0])
+                outs_v.append(self.outputs[1])
+        if collect:
+            return self.losses, torch.cat(outs_a, dim=2), torch.stack(outs_v, dim=2)
         return self.losses

@@ -125,6 +125,58 @@ def test_trainstep_equals_autograd_path_and_oracle():
         assert (diff > 5e-5).float().mean().item() <= 1e-3, (k, diff.max().item())
 
 
+def test_sliding_window_step_matches_reference_loop():
+    """TrainStep.sliding_window_step == the reference's num_seq-window optimizer step (train_avse_frames.py:143-181):
+    loss / num_seq per window, gradients accumulated, one Adam step -- run on the oracle twin with torch.optim.Adam."""
+    import maavss_amd
+    from oracle import avse_ref_cpu as orc
+    num_seq, num_frames, hpf = 3, 8, 8
+    m = dict(batch=2, frames=num_frames, width=128, fft_len=256, hops_per_frame=hpf, seed=17)
+    model, twin, _ = _build(m, precise=True)
+    orc.load_seeded(twin, m["seed"])
+    twin.train()
+    n_bins, t_tot = 129, num_frames + num_seq - 1
+    g = torch.Generator().manual_seed(23)
+    x_stft = torch.rand(2, 2, hpf * t_tot, n_bins, generator=g)
+    y_stft = torch.rand(2, 2, hpf * t_tot, n_bins, generator=g) * 0.8
+    x_attn = torch.rand(2, 1, t_tot, 128, 128, generator=g)
+    y_attn = torch.rand(2, 1, t_tot, 128, 128, generator=g)
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    opt.zero_grad()
+    mid = (num_seq - 1) // 2
+    outs = []
+    for j in range(num_seq):
+        yh_a, yh_v, _ = twin(x_stft[:, :, hpf * j:hpf * (j + num_frames)], x_attn[:, :, j:j + num_frames])
+        a_loss = torch.nn.functional.mse_loss(yh_a, y_stft[:, :, hpf * (j + mid):hpf * (j + mid + 1)])
+        v_loss = torch.nn.functional.mse_loss(yh_v, y_attn[:, :, j + mid])
+        loss = (a_loss + 0.001 * v_loss) / num_seq
+        loss.backward()
+        outs.append(yh_a.detach())
+    opt.step()
+    step = maavss_amd.TrainStep(model, lr=1e-3, loss_coeff=0.001, num_seq=num_seq)
+    losses, out_stft, out_attn = step.sliding_window_step(x_stft.cuda(), y_stft.cuda(), x_attn.cuda(), y_attn.cuda(), num_frames, hpf,
+                                                          collect=True)
+    np.testing.assert_allclose(losses.cpu().numpy(), [a_loss.item(), v_loss.item(), loss.item()], rtol=2e-4, atol=1e-6)
+    assert tuple(out_stft.shape) == (2, 2, hpf * num_seq, n_bins) and tuple(out_attn.shape) == (2, 1, num_seq, 128, 128)
+    # windows 1.. run on BatchNorm buffers the earlier windows updated, exactly as in the reference loop
+    np.testing.assert_allclose(out_stft.cpu().numpy(), torch.cat(outs, dim=2).numpy(), rtol=0, atol=5e-5)
+    ref_params = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder.") or k.startswith("stft_decoder."):
+            continue
+        diff = (p.detach().cpu() - ref_params[k].detach()).abs()
+        assert diff.max().item() <= 2.1e-3, k                      # one Adam step: |dw| <= lr, sign flips of ~0 gradients 2*lr
+        assert (diff > 5e-5).float().mean().item() <= 1e-3, (k, diff.max().item())
+    bufs = dict(twin.named_buffers())
+    for k, bbuf in model.named_buffers():
+        if k.startswith("stft_decoder.") or k.startswith("stft_autoencoder."):
+            continue
+        if k.endswith("num_batches_tracked"):
+            assert bbuf.item() == num_seq
+        else:
+            np.testing.assert_allclose(bbuf.cpu().numpy(), bufs[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 def test_adaptive_extension_224_matches_oracle():
     """224^2 is not constructible in the reference; the 'adaptive' extension is checked against the oracle twin."""
     from oracle import avse_ref_cpu as orc
