@@ -279,7 +279,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
     }
   };
   auto epi_slice = [&](int idx, int tn) {
-    const int h = idx >> 1, b = idx & 1;
+    const int b = idx >> 1, h = idx & 1;   // the two 64-byte halves of a row's 128-byte line are written back to back
     const int n = tn * PG_BN + wn * 64 + h * 32 + gq * 8;
     const int m = m0 + rowm[b];
     v2f v[4] = {v2f{prev[2 * h][b][0], prev[2 * h][b][1]} + pbias[h][0], v2f{prev[2 * h][b][2], prev[2 * h][b][3]} + pbias[h][1],
@@ -317,7 +317,10 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
       load_frags(u + 1, fw1, fx1);
       __builtin_amdgcn_sched_barrier(0);     // the reads go out BEFORE the MFMA / epilogue block (hipcc sinks them below it otherwise)
       mfmas(fw0, fx0);
-      if (have_prev && ks < 8) epi_slice(ks >> 1, prev_tn);
+      if (have_prev && (ks == 0 || ks == 4)) {
+        epi_slice(ks >> 1, prev_tn);
+        epi_slice((ks >> 1) + 1, prev_tn);
+      }
       // odd step: once its fragments are in registers the pair's slots are free -> barrier, which publishes the next pair
       PG_USE(fw1, fx1);
       if (u + 2 < total_steps) {
