@@ -50,11 +50,30 @@ __global__ void conv3d_prep_w_kernel(const float* __restrict__ w, typename Mma<P
 }
 
 // --------------------------------------------------------------------------------------------
+// XCD-aware tile order for the 16x16-output-tile kernels.  Workgroups are dealt round-robin to the 8 XCDs, each with
+// its own L2: with a plain (tx, ty, bt) grid the tiles that share input -- x / y neighbours (20x20 halo for a 16x16
+// tile) and the same tile of frames t-1, t, t+1 (three kd planes) -- land on eight different L2s and every re-read goes
+// to HBM (PMC before: 3.1 GB fetched for a 0.79 GB input by the 32->16 dgrad, 3.3-3.9x on the other layers).  Here
+// XCD k walks the k-th contiguous eighth of the tile list, tx fastest, then ty, then bt, so those re-reads meet in L2.
+struct TileId { int tx, ty, bt; int64_t lin; bool valid; };
+__device__ __forceinline__ TileId xcd_tile(int nx, int ny, int64_t total) {
+  const int64_t per = (total + 7) / 8;
+  const int64_t lin = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  TileId t;
+  t.valid = (int64_t)(blockIdx.x >> 3) < per && lin < total;
+  t.lin = lin;
+  t.tx = (int)(lin % nx);
+  t.ty = (int)((lin / nx) % ny);
+  t.bt = (int)(lin / ((int64_t)nx * ny));
+  return t;
+}
+static inline int xcd_grid(int64_t total) { return (int)(((total + 7) / 8) * 8); }
+
 template <int PRECISE, int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restrict__ x,
                                                            const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                            float* __restrict__ y, float* __restrict__ stat_partials,
-                                                           int T, int H, int W, int Ho, int Wo, int pad, int KP) {
+                                                           int n_bt, int T, int H, int W, int Ho, int Wo, int pad, int KP) {
   using M = Mma<PRECISE>;
   using E = typename M::elem;
   constexpr int ES = sizeof(E), EPC = 16 / ES;       // elements per 16-byte chunk
@@ -69,8 +88,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15;
-  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
-  const int bt = blockIdx.z, t = bt % T;
+  const TileId tile = xcd_tile((Wo + 15) / 16, (Ho + 15) / 16, (int64_t)((Wo + 15) / 16) * ((Ho + 15) / 16) * n_bt);
+  if (!tile.valid) return;
+  const int x0 = tile.tx * 16, y0 = tile.ty * 16;
+  const int bt = tile.bt, t = bt % T;
   f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -199,8 +220,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
     __syncthreads();
     if (tid < 2 * COUT) {
       const float v = red[tid] + red[2 * COUT + tid] + red[4 * COUT + tid] + red[6 * COUT + tid];
-      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      stat_partials[blk * 2 * COUT + tid] = v;
+      stat_partials[tile.lin * 2 * COUT + tid] = v;
     }
   }
 }
@@ -212,8 +232,8 @@ static int launch_igemm(const float* x, const void* wt, float* y, float* stats, 
   const size_t smem = (400 * CIN + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
   auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  dim3 grid(cdiv(Wo, 16), cdiv(Ho, 16), B * T);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, T, H, W, Ho, Wo, pad, KP);
+  const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
+  hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP);
   return 0;
 }
 
@@ -273,8 +293,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
   const int G = lane >> 4, l16 = lane & 15;
   // XCD-aware mapping: the 15 (kd,kh) blocks of one chunk walk the SAME x / dy tiles; give them 15 consecutive
   // slots of one XCD so that 14 of the 15 reads hit that XCD's L2 (measured before: 14.3 GB fetched per launch).
+  // Each XCD owns a contiguous eighth of the chunks, so chunks that re-read each other's frames (kd planes) share an L2.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int chunk = (slot / 15) * 8 + xcd, tg = slot % 15;
+  const int chunk = xcd * ((nchunk + 7) / 8) + slot / 15, tg = slot % 15;
   if (chunk >= nchunk) return;
   const int kd = tg / 5, kh = tg % 5;
   f32x4 acc[PW][NT];
@@ -450,11 +471,13 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
 // C_in = 1 (first layer): direct convolution.  x [BT][H][W], w16 [75][16] (tap-major), y [BT][H][W][16].
 __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w16,
                                                             float* __restrict__ y, float* __restrict__ stat_partials,
-                                                            int T, int H, int W) {
+                                                            int n_bt, int T, int H, int W) {
   __shared__ float halo[3][20][21];
   __shared__ float red[4][2][16];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16, bt = blockIdx.z, t = bt % T;
+  const TileId tile = xcd_tile((W + 15) / 16, (H + 15) / 16, (int64_t)((W + 15) / 16) * ((H + 15) / 16) * n_bt);
+  if (!tile.valid) return;
+  const int x0 = tile.tx * 16, y0 = tile.ty * 16, bt = tile.bt, t = bt % T;
   for (int i = tid; i < 1200; i += 256) {
     const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
     const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
@@ -499,8 +522,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
     if (tid < 32) {
       const int which = tid >> 4, c = tid & 15;
       const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      stat_partials[blk * 32 + tid] = v;
+      stat_partials[tile.lin * 32 + tid] = v;
     }
   }
 }
@@ -514,7 +536,7 @@ __global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __rest
 // dW[16][75] partial per block: thread (tap, position-phase); dy tile and x halo in LDS.
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partials, int T, int H, int W,
-                                                              int tiles_x, int tiles_y, int BT, int tiles_per_chunk) {
+                                                              int tiles_x, int tiles_y, int BT, int tiles_per_chunk, int nchunk) {
   __shared__ float halo[3][20][21];
   __shared__ __attribute__((aligned(16))) float dys[256][16];
   __shared__ float red[3][75][17];
@@ -525,7 +547,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
 #pragma unroll
   for (int c = 0; c < 16; ++c) acc[c] = 0.f;
   const int tiles_total = BT * tiles_x * tiles_y;
-  const int tile_beg = blockIdx.x * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  const int chunk = (blockIdx.x & 7) * ((nchunk + 7) / 8) + (blockIdx.x >> 3);   // contiguous chunk range per XCD (frame re-reads meet in its L2)
+  if (chunk >= nchunk) return;
+  const int tile_beg = chunk * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
   for (int tile = tile_beg; tile < tile_end; ++tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y), t = bt % T;
     const int x0 = tx * 16, y0 = ty * 16;
@@ -564,7 +588,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
   __syncthreads();
   for (int i = tid; i < 1200; i += 256) {
     const int c = i / 75, tp = i % 75;
-    partials[(int64_t)blockIdx.x * 1200 + i] = red[0][tp][c] + red[1][tp][c] + red[2][tp][c];  // [chunk][c][tap]
+    partials[(int64_t)chunk * 1200 + i] = red[0][tp][c] + red[1][tp][c] + red[2][tp][c];  // [chunk][c][tap]
   }
 }
 
@@ -582,8 +606,8 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
   MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "conv3d_c1_fwd: empty problem");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conv3d_c1_prep_kernel, dim3(5), dim3(256), 0, st, w, w16_ws);
-  hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(cdiv(W, 16), cdiv(H, 16), B * T), dim3(256), 0, st, x, w16_ws, y,
-                     stat_partials, T, H, W);
+  hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(xcd_grid((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T)), dim3(256), 0, st, x, w16_ws, y,
+                     stat_partials, B * T, T, H, W);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_kernel");
   return MAAVSS_OK;
 }
@@ -595,8 +619,8 @@ extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw
   hipStream_t st = (hipStream_t)stream;
   const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
   const int tiles_total = B * T * tiles_x * tiles_y;
-  hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(nchunk), dim3(256), 0, st, x, dy, ws, T, H, W, tiles_x, tiles_y, B * T,
-                     cdiv(tiles_total, nchunk));
+  hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy, ws, T, H, W, tiles_x, tiles_y, B * T,
+                     cdiv(tiles_total, nchunk), nchunk);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_kernel");
   hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(5), dim3(256), 0, st, ws, dw, nchunk, beta);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_reduce_kernel");

@@ -23,9 +23,11 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int G = lane >> 4, l16 = lane & 15;
   constexpr int KDG = 3 / KDN;               // kd groups (blockIdx.x % KDG)
-  // XCD-aware mapping: the KDG blocks of one chunk take consecutive slots of one XCD (shared tiles hit its L2)
+  // XCD-aware mapping: the KDG blocks of one chunk take consecutive slots of one XCD (shared tiles hit its L2), and
+  // each XCD owns a CONTIGUOUS eighth of the chunks: a chunk is about one frame of tiles, so the chunks that re-read
+  // its frames (t-1, t+1: the kd planes) run next to it on the same L2 (PMC before: 1.85x the algorithmic bytes).
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int chunk = (slot / KDG) * 8 + xcd, kdg = slot % KDG;
+  const int chunk = xcd * ((nchunk + 7) / 8) + slot / KDG, kdg = slot % KDG;
   if (chunk >= nchunk) return;
   const int kd0 = kdg * KDN;
   f32x4 acc[PW][NT];
