@@ -131,6 +131,32 @@ int maavss_convt2d_wgrad_nchunk(int B, int Hi, int Wi);
 int maavss_convt2d_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Ci, int Hi, int Wi, int Co, int kw,
                          int sh, int sw, int oph, int opw, int out_layout, int beta, void* stream);
 
+/* ---- K19 generic biased Conv2d / ConvTranspose2d of the phasegram variant avse_model.AV_Fusion_Model
+ * (avse_model.py:433,452,494,591): kernels (1,9) and (5,5), any stride / padding, <= 25 taps.
+ * A small map S [B][Hs][Ws][Cs] and a big map G [B][Hb][Wb][Cb] with by = sy*sh - ph + kh, bx = sx*sw - pw + kw and a
+ * weight w[cs][cb][kh][kw] (= Conv2d's [Co][Ci] and ConvTranspose2d's [Ci][Co]):
+ *   gen_small: S = bias + G (*) w   -- Conv2d forward, ConvTranspose2d input gradient (bias NULL)
+ *   gen_big:   G = bias + S (*)^T w -- ConvTranspose2d forward, Conv2d input gradient (bias NULL)
+ *   gen_wgrad: dw = S (x) G         -- both; ws: maavss_conv2d_gen_wgrad_nchunk(B,Hs,Ws) * Cs*Cb*kh*kw floats
+ * small_strides / big_strides: HOST arrays of 4 element strides {batch, y, x, channel} (NCHW and channels-last, also
+ * channel-padded, without copies).  channel_sum: out[c] (+)= sum_rows x[row*row_stride + c*chan_stride] (bias gradients). */
+int maavss_conv2d_gen_small(const float* big, const float* w, const float* bias, float* small, int B, int Cs, int Hs, int Ws,
+                            int Cb, int Hb, int Wb, int kh, int kw, int sh, int sw, int ph, int pw,
+                            const int64_t* small_strides, const int64_t* big_strides, void* stream);
+int maavss_conv2d_gen_big(const float* small, const float* w, const float* bias, float* big, int B, int Cs, int Hs, int Ws,
+                          int Cb, int Hb, int Wb, int kh, int kw, int sh, int sw, int ph, int pw,
+                          const int64_t* small_strides, const int64_t* big_strides, void* stream);
+int maavss_conv2d_gen_wgrad_nchunk(int B, int Hs, int Ws);
+int maavss_conv2d_gen_wgrad(const float* small, const float* big, float* dw, float* ws, int B, int Cs, int Hs, int Ws, int Cb,
+                            int Hb, int Wb, int kh, int kw, int sh, int sw, int ph, int pw, const int64_t* small_strides,
+                            const int64_t* big_strides, int beta, void* stream);
+int maavss_channel_sum(const float* x, float* out, int64_t rows, int C, int64_t row_stride, int64_t chan_stride, int beta,
+                       void* stream);
+/* Linear bias + LeakyReLU(slope) (avse_model.py:613-621,660-663): z = act(z + bias) in place over [rows][n], act 0 = none,
+ * 3 = LeakyReLU; leaky_bwd: dz = dout * (out > 0 ? 1 : slope). */
+int maavss_bias_act_fwd(float* z, const float* bias, int64_t rows, int n, int act, float slope, void* stream);
+int maavss_leaky_bwd(const float* dout, const float* out, float* dz, int64_t n, float slope, void* stream);
+
 /* ---- K12 bidirectional LSTM recurrence (hidden 256, no bias) -- avse_model_final.py:132-133,242 ----
  * gx [B][L][2][4][256] = X.W_ih^T (both directions, gate order i,f,g,o); av [B][L][512]; hp [B][L][2][256];
  * gs [B][L][2][4][256]; cs [B][L][2][256]; bwd: dav [B][L][512] -> dgx (same shape as gx), dc scratch [2][B][256]. */

@@ -162,3 +162,33 @@ extern "C" int maavss_adaptive_pool_bwd(const float* dout, float* dx, int B, int
   MAAVSS_LAUNCH_CHECK("adaptive_pool_bwd_kernel");
   return MAAVSS_OK;
 }
+
+// ---- Linear bias + LeakyReLU(slope) of the phasegram variant (avse_model.py:660-663, 613-621): z = act(z + bias) in
+// place over [rows][n]; act 0 = identity, 3 = LeakyReLU(slope).  leaky_bwd: dz = dout * (out > 0 ? 1 : slope).
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ z, const float* __restrict__ bias, int64_t total, int n,
+                                                       int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float v = z[i] + (bias ? bias[i % n] : 0.f);
+    if (act == 3) v = v > 0.f ? v : v * slope;
+    z[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                        float* __restrict__ dz, int64_t total, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    dz[i] = out[i] > 0.f ? dout[i] : dout[i] * slope;
+}
+
+extern "C" int maavss_bias_act_fwd(float* z, const float* bias, int64_t rows, int n, int act, float slope, void* stream) {
+  MAAVSS_CHECK_ARG(z && rows > 0 && n > 0 && (act == 0 || act == 3), "bias_act_fwd: bad arguments (act must be 0 or 3)");
+  hipLaunchKernelGGL(bias_act_kernel, dim3(ew_grid(rows * n)), dim3(256), 0, (hipStream_t)stream, z, bias, rows * n, n, act, slope);
+  MAAVSS_LAUNCH_CHECK("bias_act_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_leaky_bwd(const float* dout, const float* out, float* dz, int64_t n, float slope, void* stream) {
+  MAAVSS_CHECK_ARG(dout && out && dz && n > 0 && slope > 0.f, "leaky_bwd: bad arguments (slope must be > 0: the sign of out is the sign of z)");
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dout, out, dz, n, slope);
+  MAAVSS_LAUNCH_CHECK("leaky_bwd_kernel");
+  return MAAVSS_OK;
+}

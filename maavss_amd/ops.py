@@ -277,6 +277,96 @@ def convt2d_wgrad(x, dy, w_shape, stride, opad, out_nhwc):
     return dw
 
 
+# ---------------------------------------------------------------------------------------------- generic conv2d (K19)
+import ctypes as _ct
+
+ACT_LEAKY = 3
+
+
+class Map:
+    """A [B, H, W, C] view of a tensor for the generic convolution kernels: `t` is stored NHWC (possibly with more
+    channels allocated than `c`, for the BatchNorm kernels) or NCHW (the network's own tensors)."""
+
+    def __init__(self, t, nchw=False, c=None):
+        _f32(t)
+        self.t, self.nchw = t, nchw
+        if nchw:
+            self.b, self.c_alloc, self.h, self.w = t.shape
+            st = (t.stride(0), t.stride(2), t.stride(3), t.stride(1))
+        else:
+            self.b, self.h, self.w, self.c_alloc = t.shape
+            st = (t.stride(0), t.stride(1), t.stride(2), t.stride(3))
+        self.c = self.c_alloc if c is None else c
+        self.strides = (_ct.c_int64 * 4)(*st)
+
+
+def _cgen_args(small, big, w, stride, pad):
+    cs, cb, kh, kw = w.shape
+    assert small.c == cs and big.c == cb and small.b == big.b, (small.c, cs, big.c, cb)
+    return (small.b, cs, small.h, small.w, cb, big.h, big.w, kh, kw, stride[0], stride[1], pad[0], pad[1], small.strides, big.strides)
+
+
+def conv_gen_small(big, w, bias, small, stride, pad):
+    """small = bias + conv(big, w): Conv2d forward (w [Co,Ci,kh,kw]) / ConvTranspose2d input gradient (bias None)."""
+    _f32(w, bias)
+    call("maavss_conv2d_gen_small", ptr(big.t), ptr(w), ptr(bias), ptr(small.t), *_cgen_args(small, big, w, stride, pad), stream_ptr())
+
+
+def conv_gen_big(small, w, bias, big, stride, pad):
+    """big = bias + convT(small, w): ConvTranspose2d forward (w [Ci,Co,kh,kw]) / Conv2d input gradient (bias None)."""
+    _f32(w, bias)
+    call("maavss_conv2d_gen_big", ptr(small.t), ptr(w), ptr(bias), ptr(big.t), *_cgen_args(small, big, w, stride, pad), stream_ptr())
+
+
+def conv_gen_wgrad(small, big, w_shape, stride, pad, dw=None, beta=0):
+    cs, cb, kh, kw = w_shape
+    nchunk = query("maavss_conv2d_gen_wgrad_nchunk", small.b, small.h, small.w)
+    ws = torch.empty(nchunk * cs * cb * kh * kw, device=small.t.device, dtype=torch.float32)
+    if dw is None:
+        dw, beta = torch.empty(cs, cb, kh, kw, device=small.t.device, dtype=torch.float32), 0
+    assert small.c == cs and big.c == cb
+    call("maavss_conv2d_gen_wgrad", ptr(small.t), ptr(big.t), ptr(dw), ptr(ws), small.b, cs, small.h, small.w, cb, big.h, big.w, kh, kw,
+         stride[0], stride[1], pad[0], pad[1], small.strides, big.strides, int(beta), stream_ptr())
+    return dw
+
+
+def channel_sum(m, out=None, beta=0):
+    """sum over batch and positions of a Map -> [C] (bias gradient of a convolution)."""
+    if out is None:
+        out, beta = torch.empty(m.c, device=m.t.device, dtype=torch.float32), 0
+    if m.nchw:      # rows are not uniformly strided across (b, y*x): reduce per batch image
+        for bi in range(m.b):
+            call("maavss_channel_sum", ptr(m.t[bi]), ptr(out), m.h * m.w, m.c, 1, m.h * m.w, 1 if (beta or bi) else 0, stream_ptr())
+    else:
+        assert m.t.is_contiguous()
+        call("maavss_channel_sum", ptr(m.t), ptr(out), m.b * m.h * m.w, m.c, m.c_alloc, 1, int(beta), stream_ptr())
+    return out
+
+
+def rows_sum(x2d, out=None, beta=0):
+    """column sums of a contiguous [rows, n] matrix (bias gradient of a Linear layer)."""
+    _f32(x2d)
+    rows, n = x2d.shape
+    if out is None:
+        out, beta = torch.empty(n, device=x2d.device, dtype=torch.float32), 0
+    call("maavss_channel_sum", ptr(x2d), ptr(out), rows, n, n, 1, int(beta), stream_ptr())
+    return out
+
+
+def bias_act_(z, bias, act=ACT_NONE, slope=0.3):
+    _f32(z, bias)
+    rows, n = z.shape
+    call("maavss_bias_act_fwd", ptr(z), ptr(bias), rows, n, act, float(slope), stream_ptr())
+    return z
+
+
+def leaky_bwd(dout, out, slope=0.3):
+    _f32(dout, out)
+    dz = torch.empty_like(out)
+    call("maavss_leaky_bwd", ptr(dout), ptr(out), ptr(dz), out.numel(), float(slope), stream_ptr())
+    return dz
+
+
 # ---------------------------------------------------------------------------------------------- lstm
 def lstm_fwd(gx, whh_f, whh_b):
     """gx [B,L,2,4,256] -> av [B,L,512] and the saved state (hp, gs, cs)."""

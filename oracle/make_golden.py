@@ -13,6 +13,7 @@ only numbers.
 
     python oracle/make_golden.py            # writes tests/golden/avse_{P,S,L}.npz and avse_ae_{P,S}.npz
     python oracle/make_golden.py ae         # only the autoencoder fixtures (audio_ae_forward)
+    python oracle/make_golden.py avfm       # only the phasegram-variant fixtures (avse_model.AV_Fusion_Model, 8 f1)
 """
 import contextlib
 import io
@@ -151,7 +152,112 @@ def run_ae(model, y_stft):
     return out
 
 
+def _grad_summary(model, prefixes=None):
+    names, gnorm, gsample = [], [], []
+    for k, p in model.named_parameters():
+        if prefixes is not None and not k.startswith(prefixes):
+            continue
+        names.append(k)
+        if p.grad is None:
+            gnorm.append(-1.0)
+            gsample.append(np.zeros(8, np.float32))
+            continue
+        g = p.grad.detach().flatten()
+        gnorm.append(g.double().norm().item())
+        idx = (torch.arange(8, dtype=torch.long) * (g.numel() - 1)) // 7
+        gsample.append(g[idx].numpy())
+    return {"param_names": np.array(names), "grad_norm": np.array(gnorm), "grad_sample": np.stack(gsample)}
+
+
+def _bn_summary(model):
+    names, mean, var = [], [], []
+    for k, b in model.named_buffers():
+        if "autoencoder" in k:
+            continue
+        if k.endswith("running_mean"):
+            names.append(k[:-len(".running_mean")])
+            mean.append(b.double().sum().item())
+        if k.endswith("running_var"):
+            var.append(b.double().sum().item())
+    return {"bn_names": np.array(names), "bn_running_mean_sum": np.array(mean), "bn_running_var_sum": np.array(var)}
+
+
+def run_avfm(model, x_a, x_v, y_a):
+    """train_av_net.py:121-131: yh_stft, yh_pgram, fused = model(x_stft, y_phasegram); a_loss = mse(yh_pgram, y_phasegram),
+    v_loss = mse(yh_stft, y_stft) (the reference's names are swapped), loss = a_loss + v_loss; backward with every
+    parameter trainable (a superset of the trainer's frozen-encoder setting)."""
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+        p.requires_grad_(True)
+    yh_a, yh_v, fused = model(x_a, x_v)
+    loss = torch.nn.functional.mse_loss(yh_v, x_v) + torch.nn.functional.mse_loss(yh_a, y_a)
+    loss.backward()
+    out = {"a_sample": yh_a.detach().flatten()[::127].numpy(), "v_sample": yh_v.detach().flatten()[::31].numpy(),
+           "fused": fused.detach().numpy(), "loss": np.float64(loss.item())}
+    out.update(_grad_summary(model, ("phasegram_encoder.", "stft_encoder.", "lstm.", "fc1.", "fc2.", "a_fc1.", "v_fc1.")))
+    out.update(_bn_summary(model))
+    res = {"full_" + k: v for k, v in out.items()}
+    # the two autoencoder entry points (train_visual_net / train_audio_net style steps)
+    for tag, fn, x in (("vae", model.visual_ae_forward, x_v), ("aae", model.audio_ae_forward, x_a)):
+        for p in model.parameters():
+            p.grad = None
+        yh = fn(x)
+        loss = torch.nn.functional.mse_loss(yh, x)
+        loss.backward()
+        o = {"out_sample": yh.detach().flatten()[::53].numpy(), "loss": np.float64(loss.item())}
+        o.update(_grad_summary(model, ("phasegram_encoder.", "phasegram_decoder.") if tag == "vae" else ("stft_encoder.", "stft_decoder.")))
+        res.update({f"{tag}_" + k: v for k, v in o.items()})
+    return res
+
+
+def main_avfm():
+    """pin oracle/avfm_ref_cpu.py (AVFusionRef, video_phasegram_ref) to the reference."""
+    from oracle import avfm_ref_cpu as avfm
+    with reference_on_cpu():
+        with contextlib.redirect_stdout(io.StringIO()):
+            import avse_model as ref_mod
+        # utilities.py needs torchvision / cv2 / wandb (absent): video_phasegram is taken from its source text by name --
+        # executed here, in the build container only, never copied into the repo
+        import ast
+        src = open(os.path.join(REFERENCE, "utilities.py")).read()
+        fn_src = next(ast.get_source_segment(src, n) for n in ast.parse(src).body
+                      if isinstance(n, ast.FunctionDef) and n.name == "video_phasegram")
+        ns = {"torch": torch, "np": np}
+        exec(compile(fn_src, "utilities.video_phasegram", "exec"), ns)
+        b, t_a, n_bins, t, p = 2, 64, 256, 8, 32
+        stft_shape, pgram_shape = [b, 2, t_a, n_bins], [b, 1, t, p * p]
+        with contextlib.redirect_stdout(io.StringIO()):
+            torch.manual_seed(0)
+            ref = ref_mod.AV_Fusion_Model(stft_shape, pgram_shape, 8)
+        twin = avfm.AVFusionRef(stft_shape, pgram_shape, 8)
+        assert list(ref.state_dict().keys()) == list(twin.state_dict().keys()), "state_dict keys differ"
+        sd = avfm.seeded_state_dict(twin, SEED)
+        g = torch.Generator().manual_seed(SEED + 5)
+        attn = torch.rand(b, 1, t, p, p, generator=g)
+        x_v_ref = ns["video_phasegram"](attn.clone(), resize=None, diff=True, cumulative=True, normalize=True)
+        x_v = avfm.video_phasegram_ref(attn)
+        np.testing.assert_allclose(x_v.numpy(), x_v_ref.numpy(), rtol=0, atol=1e-6, err_msg="video_phasegram")
+        x_a = torch.randn(b, 2, t_a, n_bins, generator=g) * 0.5
+        y_a = torch.randn(b, 2, t_a, n_bins, generator=g) * 0.3
+        ref.load_state_dict(sd, strict=True)
+        twin.load_state_dict(sd, strict=True)
+        got_ref, got_twin = run_avfm(ref, x_a, x_v, y_a), run_avfm(twin, x_a, x_v, y_a)
+        for k in got_ref:
+            if got_ref[k].dtype.kind in "US":
+                assert (got_ref[k] == got_twin[k]).all(), k
+            else:
+                np.testing.assert_allclose(got_twin[k], got_ref[k], rtol=2e-5, atol=1e-6, err_msg=f"avfm:{k}")
+        meta = dict(batch=b, t_a=t_a, n_bins=n_bins, frames=t, p_size=p, seed=SEED)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "avfm_A.npz"), attn_sample=attn.flatten()[::97].numpy(),
+                            pgram_sample=x_v_ref.flatten()[::13].numpy(), pgram_abs_sum=np.float64(x_v_ref.double().abs().sum().item()),
+                            **got_ref, **{f"meta_{k}": np.array(v) for k, v in meta.items()})
+        print(f"[golden] avfm A: loss={got_ref['full_loss']:.8f} oracle==reference OK (model and video_phasegram)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "avfm":
+        return main_avfm()
     only_ae = len(sys.argv) > 1 and sys.argv[1] == "ae"
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     torch.set_num_threads(8)
@@ -202,6 +308,8 @@ def main():
                                 **got_ref, **{f"meta_{k}": np.array(v) for k, v in meta.items()})
             print(f"[golden] {name}: loss={got_ref['loss']:.8f} params={len(got_ref['param_names'])} "
                   f"oracle==reference OK", flush=True)
+    if not only_ae:
+        main_avfm()
 
 
 if __name__ == "__main__":

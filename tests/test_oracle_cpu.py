@@ -9,6 +9,7 @@ import torch
 from oracle import avse_ref_cpu as orc
 from oracle import stft_ref_cpu as sref
 from oracle import vit_ref_cpu as vref
+from oracle import avfm_ref_cpu as avfm
 
 
 def _load(golden_dir, name):
@@ -64,6 +65,33 @@ def test_autoencoder_oracle_matches_reference_golden(golden_dir, name):
     for i, k in enumerate(z["param_names"]):
         gn = params[str(k)].grad.double().norm().item()
         assert abs(gn - z["grad_norm"][i]) <= 1e-4 * z["grad_norm"][i] + 1e-9, k
+
+
+def test_phasegram_variant_oracle_matches_reference_golden(golden_dir):
+    """AVFusionRef + video_phasegram_ref reproduce what the reference's AV_Fusion_Model and
+    utilities.video_phasegram produced in the build container (oracle/make_golden.py avfm)."""
+    z = np.load(os.path.join(golden_dir, "avfm_A.npz"), allow_pickle=False)
+    m = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+    b, t_a, n_bins, t, p = m["batch"], m["t_a"], m["n_bins"], m["frames"], m["p_size"]
+    model = avfm.AVFusionRef([b, 2, t_a, n_bins], [b, 1, t, p * p], 8)
+    avfm.load_seeded(model, m["seed"])
+    g = torch.Generator().manual_seed(m["seed"] + 5)
+    attn = torch.rand(b, 1, t, p, p, generator=g)
+    x_v = avfm.video_phasegram_ref(attn)
+    np.testing.assert_allclose(x_v.flatten()[::13].numpy(), z["pgram_sample"], rtol=0, atol=1e-6)
+    assert abs(x_v.double().abs().sum().item() - z["pgram_abs_sum"]) < 1e-3
+    x_a = torch.randn(b, 2, t_a, n_bins, generator=g) * 0.5
+    y_a = torch.randn(b, 2, t_a, n_bins, generator=g) * 0.3
+    model.train()
+    yh_a, yh_v, fused = model(x_a, x_v)
+    loss = torch.nn.functional.mse_loss(yh_v, x_v) + torch.nn.functional.mse_loss(yh_a, y_a)
+    loss.backward()
+    np.testing.assert_allclose(fused.detach().numpy(), z["full_fused"], rtol=1e-4, atol=2e-6)
+    assert abs(loss.item() - z["full_loss"]) < 1e-6
+    params = dict(model.named_parameters())
+    for i, k in enumerate(z["full_param_names"]):
+        gn = params[str(k)].grad.double().norm().item()
+        assert abs(gn - z["full_grad_norm"][i]) <= 1e-4 * z["full_grad_norm"][i] + 1e-9, k
 
 
 def test_constructor_shapes_and_guards():
