@@ -157,6 +157,13 @@ int maavss_channel_sum(const float* x, float* out, int64_t rows, int C, int64_t 
 int maavss_bias_act_fwd(float* z, const float* bias, int64_t rows, int n, int act, float slope, void* stream);
 int maavss_leaky_bwd(const float* dout, const float* out, float* dz, int64_t n, float slope, void* stream);
 
+/* ---- K20 utilities.video_phasegram (utilities.py:206-228; train_av_net.py:122-125) ----
+ * frames [batch][T][P][P] (attention maps, P in {32, 64}); out [batch][T][P*P] (= the reference's [B,1,T,P*P]):
+ * fft2 -> fftshift over ALL axes, batch and frame included (the reference passes no dim) -> angle -> (cumulative ? cumsum / (2 pi P*P) : (angle + pi) / 2 pi) -> (diff ? temporal difference with a
+ * zero first row) -> (normalize ? / max |.| over the whole batch tensor).  p_ws [batch][T][P*P] and absmax_ws [1] are scratch. */
+int maavss_video_phasegram(const float* frames, int64_t batch, int T, int P, int diff, int cumulative, int normalize, float* p_ws,
+                           float* absmax_ws, float* out, void* stream);
+
 /* ---- K12 bidirectional LSTM recurrence (hidden 256, no bias) -- avse_model_final.py:132-133,242 ----
  * gx [B][L][2][4][256] = X.W_ih^T (both directions, gate order i,f,g,o); av [B][L][512]; hp [B][L][2][256];
  * gs [B][L][2][4][256]; cs [B][L][2][256]; bwd: dav [B][L][512] -> dgx (same shape as gx), dc scratch [2][B][256]. */

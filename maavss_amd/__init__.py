@@ -7,6 +7,7 @@ from . import _lib  # noqa: F401
 from .stft import STFT, calc_hop_size  # noqa: F401
 from .avse import AV_Fusion_Model_Frames  # noqa: F401
 from .avfm import AV_Fusion_Model  # noqa: F401
+from .phasegram import video_phasegram  # noqa: F401
 from .trainer import FusedAdam, GradSync, TrainStep, shard_batch  # noqa: F401
 from .video_attention import VideoAttention  # noqa: F401
 from .checkpoint import latest_file, load_checkpoint, save_checkpoint, save_model  # noqa: F401

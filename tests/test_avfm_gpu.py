@@ -179,3 +179,24 @@ def test_generic_conv_kernels_vs_torch(kind, ci, co, k, stride, pad, opad):
     np.testing.assert_allclose(dxt.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=3e-5)
     np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(ops.channel_sum(dym).cpu().numpy(), bias.grad.numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("p,diff,cumulative,normalize", [(32, True, True, True), (64, True, True, True), (64, False, True, True),
+                                                        (32, True, False, False), (64, False, False, True)])
+def test_video_phasegram_matches_oracle(golden_dir, p, diff, cumulative, normalize):
+    """K20 vs the oracle restatement of utilities.video_phasegram (itself checked against the reference function, and against
+    the committed samples of its output below)."""
+    import maavss_amd
+    from oracle import avfm_ref_cpu as avfm
+    g = torch.Generator().manual_seed(7 + 5)          # the fixture's inputs (seed + 5)
+    attn = torch.rand(2, 1, 8, p, p, generator=g)
+    want = avfm.video_phasegram_ref(attn, diff=diff, cumulative=cumulative, normalize=normalize)
+    got = maavss_amd.video_phasegram(attn.cuda(), resize=(p, p), diff=diff, cumulative=cumulative, normalize=normalize)
+    assert tuple(got.shape) == (2, 1, 8, p * p)
+    # the phase of a bin is ill-conditioned where the bin is small (float FFT noise / |X|); after the cumulative sum and the
+    # normalisation that is a few 1e-6 of full scale
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+    if (p, diff, cumulative, normalize) == (32, True, True, True):
+        z = np.load(os.path.join(golden_dir, "avfm_A.npz"), allow_pickle=False)
+        np.testing.assert_array_equal(attn.flatten()[::97].numpy(), z["attn_sample"])
+        np.testing.assert_allclose(got.flatten()[::13].cpu().numpy(), z["pgram_sample"], rtol=0, atol=2e-5)
