@@ -57,15 +57,29 @@ __device__ __forceinline__ bf16x8 concat4(bf16x4 lo, bf16x4 hi) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// Wave-wide reductions on the VALU (DPP), result uniform across the wave.  The __shfl_xor form goes through the LDS
+// crossbar: six dependent ds_bpermute round trips (~500 cycles per reduction, stamped in the LayerNorm prologue).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float x, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1, 0xf>(v, 0.f);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xf>(v, 0.f);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xf>(v, 0.f);   // row_half_mirror
+  v += dpp_f32<0x140, 0xf>(v, 0.f);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v += dpp_f32<0x142, 0xa>(v, 0.f);   // row_bcast:15 into rows 1, 3
+  v += dpp_f32<0x143, 0xc>(v, 0.f);   // row_bcast:31 into rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(v, v));   // masked-off rows keep their own value (old = v)
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

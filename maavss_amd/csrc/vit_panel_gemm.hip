@@ -75,22 +75,6 @@ __device__ __forceinline__ int panel_off(int r, int k) {
   return r * PG_K + (k & ~63) + ((((k & 63) >> 3) ^ (r & 7)) << 3) + (k & 7);
 }
 
-// Wave-wide f32 sum on the VALU (DPP), result uniform.  The __shfl_xor form goes through the LDS crossbar: six
-// dependent ds_bpermute round trips, ~500 cycles per reduction -- stamped at 1000 cycles per LayerNorm row.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float pg_dpp(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float pg_wave_sum(float v) {
-  v += pg_dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v += pg_dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  v += pg_dpp<0x141, 0xf>(v);   // row_half_mirror
-  v += pg_dpp<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
-  v += pg_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
-  v += pg_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3: lane 63 holds the total
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
 // LayerNorm the NP row PAIRS [r0, r0 + 2 NP) of the panel that starts at global row m0, one wave.  Two consecutive rows
 // are 768 contiguous floats = three 16-byte-per-lane loads (j = 0: row A [4l, +4); j = 1: lanes < 32 row A [256 + 4l, +4),
 // lanes >= 32 row B [4(l-32), +4); j = 2: row B [128 + 4l, +4)): half the vector-memory instructions of an 8-byte-per-lane
@@ -121,8 +105,8 @@ __device__ __forceinline__ void pg_ln_rows(const PGemmArgs& g, bf16_t* panel, in
   for (int pp = 0; pp < NP; ++pp) {
     auto sum4 = [](const float4& a) __attribute__((always_inline)) { return (a.x + a.y) + (a.z + a.w); };
     const float s0 = sum4(v[pp][0]), s1 = sum4(v[pp][1]), s2 = sum4(v[pp][2]);
-    const float meanA = pg_wave_sum(s0 + (lo ? s1 : 0.f)) * (1.f / PG_K);
-    const float meanB = pg_wave_sum(s2 + (lo ? 0.f : s1)) * (1.f / PG_K);
+    const float meanA = wave_sum(s0 + (lo ? s1 : 0.f)) * (1.f / PG_K);
+    const float meanB = wave_sum(s2 + (lo ? 0.f : s1)) * (1.f / PG_K);
     const float mean[3] = {meanA, lo ? meanA : meanB, meanB};
     float4 c[3];
     float q[3];
@@ -131,8 +115,8 @@ __device__ __forceinline__ void pg_ln_rows(const PGemmArgs& g, bf16_t* panel, in
       c[j] = make_float4(v[pp][j].x - mean[j], v[pp][j].y - mean[j], v[pp][j].z - mean[j], v[pp][j].w - mean[j]);
       q[j] = (c[j].x * c[j].x + c[j].y * c[j].y) + (c[j].z * c[j].z + c[j].w * c[j].w);
     }
-    const float rstdA = rsqrtf(pg_wave_sum(q[0] + (lo ? q[1] : 0.f)) * (1.f / PG_K) + g.ln_eps);
-    const float rstdB = rsqrtf(pg_wave_sum(q[2] + (lo ? 0.f : q[1])) * (1.f / PG_K) + g.ln_eps);
+    const float rstdA = rsqrtf(wave_sum(q[0] + (lo ? q[1] : 0.f)) * (1.f / PG_K) + g.ln_eps);
+    const float rstdB = rsqrtf(wave_sum(q[2] + (lo ? 0.f : q[1])) * (1.f / PG_K) + g.ln_eps);
     const float rstd[3] = {rstdA, lo ? rstdA : rstdB, rstdB};
     const int row[3] = {r0 + 2 * pp, r0 + 2 * pp + (lo ? 0 : 1), r0 + 2 * pp + 1};
 #pragma unroll
