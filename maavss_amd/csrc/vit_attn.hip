@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
   const int qb = slot % qblocks;
   const int head = group % heads, frame = group / heads;
   const int q0 = qb * ATT_QT + wv * 32;
+  const bool wave_active = q0 < ntok;
   const int64_t row0 = (int64_t)frame * ntok;
   const bf16_t* qbase = qkv + head * ATT_D;
   const bf16_t* kbase = qkv + dim + head * ATT_D;
@@ -92,6 +93,10 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
   for (int kt = 0; kt < ntiles; ++kt) {
     const int buf = kt & 1, kv0 = kt * ATT_KT;
     if (kt + 1 < ntiles) load_tile(kv0 + ATT_KT);
+    // A wave whose 32 query rows all lie past the sequence end (ntok = 785: three of the four waves of the last query
+    // block, 11 % of all waves) only helps staging K / V: its MFMA and softmax issue slots go to the other workgroups
+    // resident on the SIMD.
+    if (wave_active) {
     // ---- S^T = K Q^T : s[t][nt][r] = score(key 16 nt + 4 gq + r, query t*16 + l16)
     // The running row maximum goes in as the MFMA's C operand (s' = score - m_run), so no subtraction pass.
     f32x4 s[2][4];
@@ -126,8 +131,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
       float m45 = fmaxf(fmaxf(s[t][2][0], s[t][2][1]), fmaxf(s[t][2][2], s[t][2][3]));
       float m67 = fmaxf(fmaxf(s[t][3][0], s[t][3][1]), fmaxf(s[t][3][2], s[t][3][3]));
       float m = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      mx[t] = fmaxf(m, __shfl_xor(m, 32, 64));
+      // max over the four lanes (gq) of a query: lane ^ 16 and lane ^ 32 through the gfx950 lane-swap instructions
+      // (one VALU op each) instead of two ds_bpermute round trips through the LDS crossbar
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+      m = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+      mx[t] = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
     }
     const bool first = kt == 0;
     if (__any(first || mx[0] > ATT_THR || mx[1] > ATT_THR)) {
@@ -183,6 +192,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
         Mma<MODE_BF16>::mma(o[0][dt], fv, fp[0][ks]);
         Mma<MODE_BF16>::mma(o[1][dt], fv, fp[1][ks]);
       }
+    }   // wave_active
     if (kt + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
   }
