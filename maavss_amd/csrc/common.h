@@ -81,6 +81,34 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f32<0x143, 0xc>(v, v));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum / max over the four lanes {l, l^16, l^32, l^48} (the four 16-lane rows of a wave) through the gfx950 lane-swap
+// instructions -- one VALU op per exchange instead of a ds_bpermute round trip through the LDS crossbar.
+// v_permlane16_swap a, b exchanges IN PLACE the odd 16-lane rows of a with the even rows of b (v_permlane32_swap: the
+// upper half of a with the lower half of b): starting from two copies of v, a = {v0, v0, v2, v2} and b = {v1, v1, v3, v3}
+// (rows).  Written as inline asm: with this hipcc the second result of __builtin_amdgcn_permlane16_swap reads back as the
+// first one (v + v instead of v_even + v_odd in the emitted code), checked on the GPU.
+__device__ __forceinline__ void lane_swap16(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap32(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+  float a, b;
+  lane_swap16(v, a, b);
+  lane_swap32(a + b, a, b);
+  return a + b;
+}
+__device__ __forceinline__ float rows4_max(float v) {
+  float a, b;
+  lane_swap16(v, a, b);
+  lane_swap32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
   if (stat_partials != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+      s1[j] = rows4_sum(s1[j]);
+      s2[j] = rows4_sum(s2[j]);
       if (g == 0) {
         red[(wv * 2 + 0) * COUT + j * 16 + l16] = s1[j];
         red[(wv * 2 + 1) * COUT + j * 16 + l16] = s2[j];

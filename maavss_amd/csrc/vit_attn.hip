@@ -131,12 +131,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
       float m45 = fmaxf(fmaxf(s[t][2][0], s[t][2][1]), fmaxf(s[t][2][2], s[t][2][3]));
       float m67 = fmaxf(fmaxf(s[t][3][0], s[t][3][1]), fmaxf(s[t][3][2], s[t][3][3]));
       float m = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
-      // max over the four lanes (gq) of a query: lane ^ 16 and lane ^ 32 through the gfx950 lane-swap instructions
-      // (one VALU op each) instead of two ds_bpermute round trips through the LDS crossbar
-      const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-      m = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
-      const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-      mx[t] = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
+      mx[t] = rows4_max(m);   // max over the four lanes (gq) of a query: lane-swap instructions, no LDS crossbar
     }
     const bool first = kt == 0;
     if (__any(first || mx[0] > ATT_THR || mx[1] > ATT_THR)) {
@@ -200,8 +195,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float l = lrow[t];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows4_sum(l);
     const float inv = 1.f / l;
     const int qr = q0 + t * 16 + l16;
     if (qr < ntok) {
