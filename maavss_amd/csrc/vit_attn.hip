@@ -126,11 +126,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
     float mx[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float m01 = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
-      float m23 = fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3]));
-      float m45 = fmaxf(fmaxf(s[t][2][0], s[t][2][1]), fmaxf(s[t][2][2], s[t][2][3]));
-      float m67 = fmaxf(fmaxf(s[t][3][0], s[t][3][1]), fmaxf(s[t][3][2], s[t][3][3]));
-      float m = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
+      // 16 scores per lane and query: eight v_max3_f32 (three inputs per instruction) instead of fifteen v_max_f32
+      auto max3 = [](float a, float b, float c) __attribute__((always_inline)) { return fmaxf(fmaxf(a, b), c); };
+      const float a0 = max3(s[t][0][0], s[t][0][1], s[t][0][2]), a1 = max3(s[t][0][3], s[t][1][0], s[t][1][1]);
+      const float a2 = max3(s[t][1][2], s[t][1][3], s[t][2][0]), a3 = max3(s[t][2][1], s[t][2][2], s[t][2][3]);
+      const float a4 = max3(s[t][3][0], s[t][3][1], s[t][3][2]);
+      float m = max3(max3(a0, a1, a2), max3(a3, a4, s[t][3][3]), -3.0e38f);
       mx[t] = rows4_max(m);   // max over the four lanes (gq) of a query: lane-swap instructions, no LDS crossbar
     }
     const bool first = kt == 0;
