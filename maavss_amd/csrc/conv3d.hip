@@ -402,13 +402,33 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 }
 
 // dW[co][ci][kd][kh][kw] (+)= sum_chunk partials[chunk][kd*5+kh][kw][ci][co]
-__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int CI,
+// Sum of the per-chunk partials: 16 outputs x 16 chunk phases per 256-thread block (one thread per output walking all
+// chunks serially took 70-260 us per layer).
+__device__ __forceinline__ float chunk_sum16(const float* __restrict__ partials, int64_t total, int nchunk, int i0, bool& owner, int& i) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  i = i0 + o;
+  float s = 0.f;
+  if (i < total)
+    for (int c = ph; c < nchunk; c += 16) s += partials[(int64_t)c * total + i];
+  red[ph][o] = s;
+  __syncthreads();
+  owner = ph == 0 && i < total;
+  float t = 0.f;
+  if (owner)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][o];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int CI,
                                            int CO, int beta) {
   const int total = 75 * CI * CO;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  bool owner;
+  int i;
+  const float s = chunk_sum16(partials, total, nchunk, blockIdx.x * 16, owner, i);
+  if (owner) {
     const int co = i % CO, ci = (i / CO) % CI, tap = i / (CO * CI);  // tap = (kd*5+kh)*5+kw
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * total + i];
     float* d = dw + ((int64_t)co * CI + ci) * 75 + tap;
     *d = beta ? *d + s : s;
   }
@@ -446,7 +466,7 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
   // the two large-M layers use the wide kernel (conv3d_wgrad_wide.hip): every tile staged once / three times
   if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, st)) {
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_wide_kernel");
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * c_in * c_out, 256)), dim3(256), 0, st, ws, dw, nchunk, c_in,
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * c_in * c_out, 16)), dim3(256), 0, st, ws, dw, nchunk, c_in,
                        c_out, beta);
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_reduce_kernel");
     return MAAVSS_OK;
@@ -457,7 +477,7 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
     else if (precise == MODE_F16) launch_wgrad<MODE_F16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
     else launch_wgrad<MODE_BF16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_kernel");                                              \
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * CI * CO, 256)), dim3(256), 0, st, ws, dw, nchunk, CI, CO, beta); \
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * CI * CO, 16)), dim3(256), 0, st, ws, dw, nchunk, CI, CO, beta); \
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_reduce_kernel");                                       \
     return MAAVSS_OK;                                                                        \
   }
@@ -592,12 +612,11 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
   }
 }
 
-__global__ void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 1200) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * 1200 + i];
-  dw[i] = beta ? dw[i] + s : s;
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
+  bool owner;
+  int i;
+  const float s = chunk_sum16(partials, 1200, nchunk, blockIdx.x * 16, owner, i);
+  if (owner) dw[i] = beta ? dw[i] + s : s;
 }
 
 extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B,
@@ -622,7 +641,7 @@ extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw
   hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy, ws, T, H, W, tiles_x, tiles_y, B * T,
                      cdiv(tiles_total, nchunk), nchunk);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_kernel");
-  hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(5), dim3(256), 0, st, ws, dw, nchunk, beta);
+  hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(75), dim3(256), 0, st, ws, dw, nchunk, beta);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_reduce_kernel");
   return MAAVSS_OK;
 }
