@@ -553,19 +553,25 @@ __global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __rest
   if (i < 1200) w16[i] = w[(i % 16) * 75 + i / 16];
 }
 
-// dW[16][75] partial per block: thread (tap, position-phase); dy tile and x halo in LDS.
+// dW[16][75] partial per block; dy tile and x halo in LDS.  Thread = ((kd,kh) pair, 4-channel group, row worker): it walks
+// rows of the 16x16 tile keeping the five x values of the kw window in registers (one new LDS value per position) and
+// reading its 4 dy channels once per position -- 20 FMAs per 2 LDS reads.  (The first version, one thread per tap
+// reading all 16 channels, spent 5 LDS reads per 16 FMAs and was LDS-bound at 17 us per tile.)
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partials, int T, int H, int W,
                                                               int tiles_x, int tiles_y, int BT, int tiles_per_chunk, int nchunk) {
   __shared__ float halo[3][20][21];
-  __shared__ __attribute__((aligned(16))) float dys[256][16];
-  __shared__ float red[3][75][17];
+  __shared__ __attribute__((aligned(16))) float buf[4 * 1200];   // dy tile [256][16]; at the end the cross-worker reduction [4][1200]
+  float (*dys)[16] = reinterpret_cast<float (*)[16]>(buf);
   const int tid = threadIdx.x;
-  const int tap = tid % 75, ph = tid / 75;  // ph 0..2 active, ph==3 (tid>=225) idle in the MAC loop
-  const int kd = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
-  float acc[16];
+  const bool active = tid < 240;
+  const int worker = tid / 60, q = tid % 60, khd = q >> 2, c4 = (q & 3) * 4;
+  const int kd = khd / 5, kh = khd % 5;
+  float acc[5][4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
   const int tiles_total = BT * tiles_x * tiles_y;
   const int chunk = (blockIdx.x & 7) * ((nchunk + 7) / 8) + (blockIdx.x >> 3);   // contiguous chunk range per XCD (frame re-reads meet in its L2)
   if (chunk >= nchunk) return;
@@ -582,34 +588,43 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
       halo[d][r][c] = v;
     }
     for (int i = tid; i < 1024; i += 256) {
-      const int pos = i >> 2, c4 = (i & 3) * 4;
+      const int pos = i >> 2, cc = (i & 3) * 4;
       const int oy = y0 + (pos >> 4), ox = x0 + (pos & 15);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < H && ox < W) v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + c4);
-      *reinterpret_cast<float4*>(&dys[pos][c4]) = v;
+      if (oy < H && ox < W) v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
+      *reinterpret_cast<float4*>(&dys[pos][cc]) = v;
     }
     __syncthreads();
-    if (ph < 3) {
-      for (int pos = ph; pos < 256; pos += 3) {
-        const float xv = halo[kd][(pos >> 4) + kh][(pos & 15) + kw];
-        const float4* d4 = reinterpret_cast<const float4*>(&dys[pos][0]);
-        const float4 a = d4[0], b = d4[1], c = d4[2], d = d4[3];
-        acc[0] = fmaf(xv, a.x, acc[0]); acc[1] = fmaf(xv, a.y, acc[1]); acc[2] = fmaf(xv, a.z, acc[2]); acc[3] = fmaf(xv, a.w, acc[3]);
-        acc[4] = fmaf(xv, b.x, acc[4]); acc[5] = fmaf(xv, b.y, acc[5]); acc[6] = fmaf(xv, b.z, acc[6]); acc[7] = fmaf(xv, b.w, acc[7]);
-        acc[8] = fmaf(xv, c.x, acc[8]); acc[9] = fmaf(xv, c.y, acc[9]); acc[10] = fmaf(xv, c.z, acc[10]); acc[11] = fmaf(xv, c.w, acc[11]);
-        acc[12] = fmaf(xv, d.x, acc[12]); acc[13] = fmaf(xv, d.y, acc[13]); acc[14] = fmaf(xv, d.z, acc[14]); acc[15] = fmaf(xv, d.w, acc[15]);
+    if (active) {
+      for (int ry = worker; ry < 16; ry += 4) {
+        const float* xr = &halo[kd][ry + kh][0];
+        float w[5] = {xr[0], xr[1], xr[2], xr[3], 0.f};
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          w[4] = xr[p + 4];
+          const float4 d = *reinterpret_cast<const float4*>(&dys[ry * 16 + p][c4]);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            acc[k][0] = fmaf(w[k], d.x, acc[k][0]);
+            acc[k][1] = fmaf(w[k], d.y, acc[k][1]);
+            acc[k][2] = fmaf(w[k], d.z, acc[k][2]);
+            acc[k][3] = fmaf(w[k], d.w, acc[k][3]);
+          }
+          w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4];
+        }
       }
     }
   }
   __syncthreads();
-  if (ph < 3)
+  float* red = buf;                        // [4 workers][16 c][75 taps]
+  if (active)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) red[ph][tap][c] = acc[c];
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[(worker * 16 + c4 + c) * 75 + khd * 5 + k] = acc[k][c];
   __syncthreads();
-  for (int i = tid; i < 1200; i += 256) {
-    const int c = i / 75, tp = i % 75;
-    partials[(int64_t)chunk * 1200 + i] = red[0][tp][c] + red[1][tp][c] + red[2][tp][c];  // [chunk][c][tap]
-  }
+  for (int i = tid; i < 1200; i += 256)     // i = c * 75 + tap: [chunk][c][tap]
+    partials[(int64_t)chunk * 1200 + i] = red[i] + red[1200 + i] + red[2400 + i] + red[3600 + i];
 }
 
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
