@@ -42,6 +42,7 @@ struct PGemmArgs {
   int qscale_cols;
   float qscale;
   int panels;
+  int full, split;   // workgroups [0, full): whole panels; the rest: panels of the tail round, `split` workgroups each
 };
 
 __device__ __forceinline__ void pg_glds16(const void* g, void* lds) {
@@ -136,8 +137,17 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l16 = lane & 15, gq = lane >> 4;
   const int wn = (wv >> 2) & 1, wm = wv & 3;   // wave tile: 64 output columns (n) x 32 rows (m)
-  const int m0 = blockIdx.x * PG_BM;
-  const int ntiles = g.N / PG_BN;
+  // Work split.  Workgroups [0, full) take one panel and all N tiles each.  The panels of the last, partly filled round
+  // (panels mod #CUs of them: 68 of 3140 on 256 CUs, a round that would leave 188 CUs idle for a whole panel time) are
+  // split over `split` workgroups that each build the panel and take a contiguous share of its N tiles.
+  int pidx = blockIdx.x, tn0 = 0, ntiles = g.N / PG_BN;
+  if ((int)blockIdx.x >= g.full) {
+    const int idx = (int)blockIdx.x - g.full, part = idx % g.split;
+    pidx = g.full + idx / g.split;
+    tn0 = part * ntiles / g.split;
+    ntiles = (part + 1) * ntiles / g.split - tn0;
+  }
+  const int m0 = pidx * PG_BM;
   const int total_steps = ntiles * PG_NKS;
 
   // ---- weight stream: four dedicated loader waves (one per SIMD), two 1-KiB pieces each per step.  Dedicated
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   const int lw = wv - PG_MMA_WAVES;   // loader index (negative on MFMA waves)
   const bf16_t* wsrc = g.W + (int64_t)(srow + lw * 32) * PG_K + ((schunk ^ ((srow >> 2) & 3)) * 8);
   auto stage = [&](int u) {   // virtual step u = tile * 12 + kstep -> ring slot u % 8; this loader's rows [32 lw, +32)
-    const int tn = u / PG_NKS, ks = u - tn * PG_NKS;
+    const int tl = u / PG_NKS, ks = u - tl * PG_NKS, tn = tn0 + tl;
     bf16_t* lb = ring + (u % PG_STAGES) * PG_BTILE_ELEMS + lw * 32 * PG_BK + lane * 8;
     const bf16_t* src = wsrc + (int64_t)tn * PG_BN * PG_K + ks * PG_BK;
 #pragma unroll
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   };
 
   int u = 0;
-  for (int tn = 0; tn < ntiles; ++tn) {
+  for (int tn = tn0; tn < tn0 + ntiles; ++tn) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -344,7 +354,22 @@ extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, con
   g.qscale_cols = qscale_cols; g.qscale = qscale; g.panels = cdiv(M, PG_BM);
   const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t);   // 96 + 64 = 160 KiB: all of a CU's LDS
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(g.panels), block(PG_THREADS);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess, "vit_panel_gemm: cannot query the device");
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int tail = g.panels % n_cu;        // one workgroup per CU (160 KiB of LDS): panels run in rounds of n_cu
+  g.full = g.panels - tail;
+  g.split = 1;
+  if (tail > 0) {
+    g.split = n_cu / tail;
+    if (g.split > N / PG_BN) g.split = N / PG_BN;
+    if (g.split < 1) g.split = 1;
+  }
+  const dim3 grid(g.full + tail * g.split), block(PG_THREADS);
 #define PG_LAUNCH(E, L)                                                                                              \
   {                                                                                                                  \
     static bool set = false;                                                                                         \
