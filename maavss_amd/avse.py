@@ -550,9 +550,20 @@ class AV_Fusion_Model_Frames(nn.Module):
             else:
                 dout, out = dcur, s["out"]
             gw, gb, acc = bn_grads("visual_encoder", 4 * i + 1)
+            wname = f"visual_encoder.{4 * i}.weight"
+            if i == 0:
+                # first layer: the network input needs no gradient, so dy has one consumer, the weight gradient -- which
+                # forms it in its loader from the pooled gradient (no 1.6 GB dy tensor, no dx pass)
+                coef = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
+                                           ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, coef_only=True)
+                if need.get(wname, False):
+                    buf, beta = gbuf(wname)
+                    ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
+                                           dw=buf, beta=beta)
+                    out_grads[wname] = buf
+                continue
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
                                      ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc)
-            wname = f"visual_encoder.{4 * i}.weight"
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:

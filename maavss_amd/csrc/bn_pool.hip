@@ -355,7 +355,7 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
                                       float* dgamma, float* dbeta, int accumulate, float* ws, int B, int T, int H, int W,
                                       int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
                                       void* stream) {
-  MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && dy && ws, "bn_pool_act_bwd: null pointer");
+  MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && ws, "bn_pool_act_bwd: null pointer");
   if (int rc = check_geom("bn_pool_act_bwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_bwd: argmax buffer required when pool > 1");
   hipStream_t st = (hipStream_t)stream;
@@ -370,6 +370,7 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, ws, nblk, C, count, gamma, invstd, dgamma, dbeta,
                      accumulate, coef);
   MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+  if (dy == nullptr) return MAAVSS_OK;   // the consumer applies the coefficients itself (maavss_conv3d_c1_wgrad_bn)
   const int64_t total = (int64_t)g.BT * H * W * (C / 4);
   hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
                      (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);

@@ -557,9 +557,23 @@ __global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __rest
 // rows of the 16x16 tile keeping the five x values of the kw window in registers (one new LDS value per position) and
 // reading its 4 dy channels once per position -- 20 FMAs per 2 LDS reads.  (The first version, one thread per tap
 // reading all 16 channels, spent 5 LDS reads per 16 FMAs and was LDS-bound at 17 us per tile.)
+// FUSE_BN: `dy` is the pre-BatchNorm conv output y and the gradient is formed on the way into LDS from the pooled
+// gradient / output / argmax and the BatchNorm backward coefficients -- the bn_pool_act_bwd_dx pass of the first layer
+// (whose only consumer is this kernel: the network input needs no gradient) and its 1.6 GB dy round trip disappear.
+struct C1BnArgs {
+  const float* dout;            // [BT][Hp][Wp][16] gradient of the pooled, activated output
+  const float* out;             // [BT][Hp][Wp][16] that output
+  const unsigned char* argmax;  // [BT][Hp][Wp][16] window position of the maximum
+  const float* mean;
+  const float* invstd;
+  const float* coef;            // [3][16]: gamma*invstd, mean(dz), mean(dz*xhat)   (bn_bwd_finalize_kernel)
+  int pool, Hp, Wp;
+};
+template <bool FUSE_BN>
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partials, int T, int H, int W,
-                                                              int tiles_x, int tiles_y, int BT, int tiles_per_chunk, int nchunk) {
+                                                              int tiles_x, int tiles_y, int BT, int tiles_per_chunk, int nchunk,
+                                                              C1BnArgs bn) {
   __shared__ float halo[3][20][21];
   __shared__ __attribute__((aligned(16))) float buf[4 * 1200];   // dy tile [256][16]; at the end the cross-worker reduction [4][1200]
   float (*dys)[16] = reinterpret_cast<float (*)[16]>(buf);
@@ -591,7 +605,33 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
       const int pos = i >> 2, cc = (i & 3) * 4;
       const int oy = y0 + (pos >> 4), ox = x0 + (pos & 15);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < H && ox < W) v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
+      if (oy < H && ox < W) {
+        v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
+        if constexpr (FUSE_BN) {
+          // same arithmetic as bn_pool_act_bwd_dx_kernel (bn_pool.hip), LeakyReLU(0.01) + max pool
+          const int py = oy / bn.pool, px = ox / bn.pool;
+          float gg[4] = {0.f, 0.f, 0.f, 0.f};
+          if (py < bn.Hp && px < bn.Wp) {
+            const int64_t pp = (((int64_t)bt * bn.Hp + py) * bn.Wp + px) * 16 + cc;
+            const int here = (oy - py * bn.pool) * bn.pool + (ox - px * bn.pool);
+            const uchar4 am = *reinterpret_cast<const uchar4*>(bn.argmax + pp);
+            if (am.x == here || am.y == here || am.z == here || am.w == here) {
+              const float4 dv = *reinterpret_cast<const float4*>(bn.dout + pp), ov = *reinterpret_cast<const float4*>(bn.out + pp);
+              if (am.x == here) gg[0] = dv.x * (ov.x > 0.f ? 1.f : 0.01f);
+              if (am.y == here) gg[1] = dv.y * (ov.y > 0.f ? 1.f : 0.01f);
+              if (am.z == here) gg[2] = dv.z * (ov.z > 0.f ? 1.f : 0.01f);
+              if (am.w == here) gg[3] = dv.w * (ov.w > 0.f ? 1.f : 0.01f);
+            }
+          }
+          const float4 mu = *reinterpret_cast<const float4*>(bn.mean + cc), is = *reinterpret_cast<const float4*>(bn.invstd + cc);
+          const float4 k0 = *reinterpret_cast<const float4*>(bn.coef + cc), k1 = *reinterpret_cast<const float4*>(bn.coef + 16 + cc);
+          const float4 k2 = *reinterpret_cast<const float4*>(bn.coef + 32 + cc);
+          v.x = k0.x * (gg[0] - k1.x - (v.x - mu.x) * is.x * k2.x);
+          v.y = k0.y * (gg[1] - k1.y - (v.y - mu.y) * is.y * k2.y);
+          v.z = k0.z * (gg[2] - k1.z - (v.z - mu.z) * is.z * k2.z);
+          v.w = k0.w * (gg[3] - k1.w - (v.w - mu.w) * is.w * k2.w);
+        }
+      }
       *reinterpret_cast<float4*>(&dys[pos][cc]) = v;
     }
     __syncthreads();
@@ -646,17 +686,37 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
   return MAAVSS_OK;
 }
 
-extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T,
-                                      int H, int W, int beta, void* stream) {
-  MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_c1_wgrad: null pointer");
-  MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0, "conv3d_c1_wgrad: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
+static int c1_wgrad_launch(const float* x, const float* dy_or_y, float* dw, float* ws, int nchunk, int B, int T, int H, int W, int beta,
+                           const C1BnArgs* bn, hipStream_t st) {
   const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
   const int tiles_total = B * T * tiles_x * tiles_y;
-  hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy, ws, T, H, W, tiles_x, tiles_y, B * T,
-                     cdiv(tiles_total, nchunk), nchunk);
+  C1BnArgs none = {};
+  if (bn)
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel<true>, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy_or_y, ws, T, H, W, tiles_x, tiles_y,
+                       B * T, cdiv(tiles_total, nchunk), nchunk, *bn);
+  else
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel<false>, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy_or_y, ws, T, H, W, tiles_x, tiles_y,
+                       B * T, cdiv(tiles_total, nchunk), nchunk, none);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_kernel");
   hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(75), dim3(256), 0, st, ws, dw, nchunk, beta);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_reduce_kernel");
   return MAAVSS_OK;
+}
+
+extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T,
+                                      int H, int W, int beta, void* stream) {
+  MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_c1_wgrad: null pointer");
+  MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0, "conv3d_c1_wgrad: bad sizes");
+  return c1_wgrad_launch(x, dy, dw, ws, nchunk, B, T, H, W, beta, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout, const float* out, const void* argmax,
+                                         const float* mean, const float* invstd, const float* coef, int pool, float* dw, float* ws,
+                                         int nchunk, int B, int T, int H, int W, int beta, void* stream) {
+  MAAVSS_CHECK_ARG(x && y && dout && out && argmax && mean && invstd && coef && dw && ws, "conv3d_c1_wgrad_bn: null pointer");
+  MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn: bad sizes (pool must be 2 or 3)");
+  C1BnArgs bn;
+  bn.dout = dout; bn.out = out; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
+  bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
+  return c1_wgrad_launch(x, y, dw, ws, nchunk, B, T, H, W, beta, &bn, (hipStream_t)stream);
 }

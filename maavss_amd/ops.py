@@ -123,6 +123,21 @@ def conv3d_c1_wgrad(x, dy, dw=None, beta=0, nchunk=None):
     return dw
 
 
+def conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, dw=None, beta=0, nchunk=None):
+    """first-layer weight gradient straight from the pooled gradient: BN / max-pool / LeakyReLU backward in the loader."""
+    _f32(x, y, dout, out, mean, invstd, coef, dw)
+    b, t, h, wd = x.shape
+    assert y.shape == (b, t, h, wd, 16) and dout.is_contiguous() and out.is_contiguous()
+    if nchunk is None:
+        nchunk = max(1, min(1024, (b * t * ((h + 15) // 16) * ((wd + 15) // 16)) // 2))
+    ws = torch.empty(nchunk * 1200, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw, beta = torch.empty(16, 1, 3, 5, 5, device=x.device, dtype=torch.float32), 0
+    call("maavss_conv3d_c1_wgrad_bn", ptr(x), ptr(y), ptr(dout), ptr(out), ptr(arg), ptr(mean), ptr(invstd), ptr(coef), pool, ptr(dw),
+         ptr(ws), nchunk, b, t, h, wd, int(beta), stream_ptr())
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------- batch norm
 def bn_stats(y2d_rows, c):
     """y: any contiguous channels-last tensor with last dim c -> partial sums [nblk,2,c]."""
@@ -174,7 +189,7 @@ def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=N
 
 
 def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,
-                    accumulate=False, dy=None):
+                    accumulate=False, dy=None, coef_only=False):
     _f32(y, mean, invstd, gamma)
     b, t, h, w, c = y.shape
     hp, wp = h // pool, w // pool
@@ -182,11 +197,13 @@ def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=N
         strides = cl_strides(t, hp, wp, c)
     nblk = query("maavss_bn_stats_nblk", b * t * hp * wp)
     ws = torch.empty(2 * c * nblk + 3 * c, device=y.device, dtype=torch.float32)
-    if dy is None:
+    if dy is None and not coef_only:
         dy = torch.empty_like(y)
     call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(dy),
          ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), b, t, h, w, c, pool, act, *[int(s) for s in strides],
          stream_ptr())
+    if coef_only:      # dgamma / dbeta done; the consumer folds dx in (conv3d_c1_wgrad_bn): [3, C] coefficients
+        return ws[2 * c * nblk:].view(3, c)
     return dy
 
 
