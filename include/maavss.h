@@ -107,8 +107,11 @@ int maavss_bn_eval_stats(const float* running_mean, const float* running_var, fl
 int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C, int pool,
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+/* beta (nullable): with it, LeakyReLU layers recover the normalised input at the pooled maximum from `out` instead of
+ * gathering it from y (xhat = (leaky^-1(out) - beta) / gamma; channels with |gamma| < 1e-2 still gather).  dy NULL: only
+ * dgamma / dbeta and the coefficients (see maavss_conv3d_c1_wgrad_bn). */
 int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
-                           const float* mean, const float* invstd, const float* gamma, float* dy, float* dgamma,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, float* dy, float* dgamma,
                            float* dbeta, int accumulate, float* ws, int B, int T, int H, int W, int C, int pool,
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
 

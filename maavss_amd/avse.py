@@ -555,7 +555,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 # first layer: the network input needs no gradient, so dy has one consumer, the weight gradient -- which
                 # forms it in its loader from the pooled gradient (no 1.6 GB dy tensor, no dx pass)
                 coef = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
-                                           ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, coef_only=True)
+                                           ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(), coef_only=True)
                 if need.get(wname, False):
                     buf, beta = gbuf(wname)
                     ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
@@ -563,7 +563,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                     out_grads[wname] = buf
                 continue
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
-                                     ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc)
+                                     ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach())
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:

@@ -11,6 +11,7 @@
 #include "common.h"
 
 #define ACT_LEAKY 0
+#define BN_INV_MIN_GAMMA 1e-2f
 #define ACT_TANH 1
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partials,
@@ -163,8 +164,13 @@ __device__ __forceinline__ void load4_strided(const float* p, int64_t stride, fl
 __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
     const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ partials, PoolGeom g, int act, int64_t rows_per_block) {
+    const float* __restrict__ gamma_inv, float* __restrict__ partials, PoolGeom g, int act, int64_t rows_per_block) {
   // rows = pooled positions; thread -> (4 channels, row phase)
+  // gamma_inv != null (LeakyReLU layers, beta known to the finalize kernel): the normalised input at the argmax is not
+  // gathered from y -- a scattered read of nearly every line of the largest tensors of the step -- but recovered from
+  // the pooled output, z = leaky^-1(out) = gamma * xhat + beta: the sum S2' = sum dz * z is accumulated here and turned
+  // into sum dz * xhat = (S2' - beta * S1) / gamma by bn_bwd_finalize_kernel.  Channels with |gamma| < BN_INV_MIN_GAMMA
+  // (xhat not recoverable) keep the gather.
   __shared__ float4 red[2][256];
   const int tid = threadIdx.x, C = g.C, C4 = C >> 2, c = (tid % C4) * 4, ph = tid / C4, nph = 256 / C4;
   const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
@@ -172,6 +178,10 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
   const float4 mu4 = *reinterpret_cast<const float4*>(mean + c), is4 = *reinterpret_cast<const float4*>(invstd + c);
   const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  bool inv[4] = {false, false, false, false};
+  if (gamma_inv != nullptr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) inv[e] = fabsf(gamma_inv[c + e]) >= BN_INV_MIN_GAMMA;
   for (int64_t pos = r0 + ph; pos < r1; pos += nph) {
     const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
     const int b = bt / g.T, t = bt % g.T;
@@ -185,8 +195,13 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gg = dv[e] * act_bwd_from_out(ov[e], act);
-      const int iy = py * g.p + bi[e] / g.p, ix = px * g.p + bi[e] % g.p;
-      const float xh = (y[(((int64_t)bt * g.H + iy) * g.W + ix) * C + c + e] - mu[e]) * is[e];
+      float xh;
+      if (inv[e]) {
+        xh = ov[e] > 0.f ? ov[e] : ov[e] * 100.f;          // z = LeakyReLU(0.01)^-1 (out)
+      } else {
+        const int iy = py * g.p + bi[e] / g.p, ix = px * g.p + bi[e] % g.p;
+        xh = (y[(((int64_t)bt * g.H + iy) * g.W + ix) * C + c + e] - mu[e]) * is[e];
+      }
       s1[e] += gg;
       s2[e] += gg * xh;
     }
@@ -210,11 +225,12 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, const float* __restrict__ beta_inv) {
   double s1, s2;
   bn_sum_partials(partials, nblk, C, s1, s2);
   const int c = threadIdx.x;
   if (c >= C) return;
+  if (beta_inv != nullptr && fabsf(gamma[c]) >= BN_INV_MIN_GAMMA) s2 = (s2 - (double)beta_inv[c] * s1) / (double)gamma[c];
   if (dgamma != nullptr) {
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
@@ -351,7 +367,7 @@ extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const f
 
 // ws: at least (2*C*nblk + 3*C) floats with nblk = maavss_bn_stats_nblk(B*T*Hp*Wp); coef = ws + 2*C*nblk
 extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
-                                      const float* mean, const float* invstd, const float* gamma, float* dy,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta, float* dy,
                                       float* dgamma, float* dbeta, int accumulate, float* ws, int B, int T, int H, int W,
                                       int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
                                       void* stream) {
@@ -363,12 +379,13 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
   const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
   const int nblk = maavss_bn_stats_nblk(rows);
   float* coef = ws + (int64_t)2 * C * nblk;
+  const bool inverse = beta != nullptr && act == ACT_LEAKY;   // tanh^-1 is ill-conditioned near +-1: those layers gather
   hipLaunchKernelGGL(bn_pool_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dout, out, (const unsigned char*)argmax,
-                     y, mean, invstd, ws, g, act, (int64_t)cdiv(rows, nblk));
+                     y, mean, invstd, inverse ? gamma : nullptr, ws, g, act, (int64_t)cdiv(rows, nblk));
   MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_reduce_kernel");
   const double count = (double)g.BT * H * W;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, ws, nblk, C, count, gamma, invstd, dgamma, dbeta,
-                     accumulate, coef);
+                     accumulate, coef, inverse ? beta : nullptr);
   MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_kernel");
   if (dy == nullptr) return MAAVSS_OK;   // the consumer applies the coefficients itself (maavss_conv3d_c1_wgrad_bn)
   const int64_t total = (int64_t)g.BT * H * W * (C / 4);

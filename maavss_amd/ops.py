@@ -189,7 +189,7 @@ def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=N
 
 
 def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,
-                    accumulate=False, dy=None, coef_only=False):
+                    accumulate=False, dy=None, coef_only=False, beta=None):
     _f32(y, mean, invstd, gamma)
     b, t, h, w, c = y.shape
     hp, wp = h // pool, w // pool
@@ -199,7 +199,8 @@ def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=N
     ws = torch.empty(2 * c * nblk + 3 * c, device=y.device, dtype=torch.float32)
     if dy is None and not coef_only:
         dy = torch.empty_like(y)
-    call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(dy),
+    _f32(beta)
+    call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(dy),
          ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), b, t, h, w, c, pool, act, *[int(s) for s in strides],
          stream_ptr())
     if coef_only:      # dgamma / dbeta done; the consumer folds dx in (conv3d_c1_wgrad_bn): [3, C] coefficients
