@@ -166,6 +166,25 @@ def test_bn_pool_act(c, pool, act, h, w):
     close(from_cl(dy), gy, 1e-4, 2e-5)
     close(dgamma, gg, 1e-4, 1e-4)
     close(dbeta, gb, 1e-4, 1e-4)
+    # with beta: LeakyReLU layers recover xhat at the pooled maximum from `out` instead of gathering y (same numbers);
+    # one channel with gamma ~ 0 has to keep the gather
+    gam2 = gamma.detach().clone()
+    gam2[1] = 1e-4
+    for gam in (gamma.detach(), gam2):
+        z2 = F.batch_norm(y.detach(), None, None, gam, beta.detach(), training=True, eps=1e-5).requires_grad_(False)
+        yq, gq, bq = y.detach().clone().requires_grad_(True), gam.clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        zz = F.batch_norm(yq, None, None, gq, bq, training=True, eps=1e-5)
+        if pool > 1:
+            zz = F.max_pool3d(zz, (1, pool, pool))
+        oo = torch.tanh(zz) if act == 1 else F.leaky_relu(zz, 0.01)
+        gy2, gg2, gb2 = torch.autograd.grad(oo, (yq, gq, bq), dout)
+        out2, arg2 = ops.bn_pool_act_fwd(y_cl, mean, invstd, gam.cuda(), beta.detach().cuda(), pool, act)
+        dg2, db2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        dy2 = ops.bn_pool_act_bwd(to_cl(dout).cuda(), out2, arg2, y_cl, mean, invstd, gam.cuda(), pool, act, dgamma=dg2, dbeta=db2,
+                                  beta=beta.detach().cuda())
+        close(from_cl(dy2), gy2, 1e-4, 2e-5)
+        close(dg2, gg2, 1e-4, 1e-4)
+        close(db2, gb2, 1e-4, 1e-4)
 
 
 def test_bn_pool_strided_output():
