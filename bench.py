@@ -250,6 +250,29 @@ def main():
                             "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                             "share_of_kernel_time": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3)}
                 break
+        # ---- the stages BASELINE.json's north star names explicitly: attention against the MFMA peak, the STFT path and
+        # the other streaming kernels against HBM (algorithmic work / HIP-event time of the timed region)
+        stages = {}
+        def stage_row(name, flops=0.0, bytes_=0.0):
+            d = summ.get(name)
+            if not d or d["ms"] <= 0:
+                return
+            sec = d["ms"] * 1e-3
+            row = {"ms_per_step": round(d["ms"] / args.steps, 3), "launches_per_step": d["calls"] // args.steps}
+            if flops:
+                row.update(tflops=round(flops / sec / 1e12, 1), mfma_frac=round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4))
+            if bytes_:
+                row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
+            stages[name.replace("maavss_", "")] = row
+        for nm in ("maavss_vit_attn", "maavss_vit_panel_gemm", "maavss_vit_gemm"):
+            if nm in summ:
+                stage_row(nm, sum(flops_of(nm, a) for a in summ[nm]["args"]), sum(bytes_of(nm, a) for a in summ[nm]["args"]))
+        if "maavss_stft_fwd" in summ:      # audio in (4 B/sample) + y and x out (2 planes x T_a x F x 4 B each)
+            a0 = summ["maavss_stft_fwd"]["args"][0]
+            per = a0[1] * (4.0 * a0[2] + 2 * 2.0 * a0[7] * a0[8] * 4.0)
+            stage_row("maavss_stft_fwd", bytes_=per * summ["maavss_stft_fwd"]["calls"])
+        if "maavss_adam_step" in summ:     # p, g, m, v read + p, m, v written: 28 B per parameter
+            stage_row("maavss_adam_step", bytes_=sum(28.0 * a[4] for a in summ["maavss_adam_step"]["args"]))
         # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs of this same command; FETCH doubled per the gfx950 guide) -- null if absent.
         pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
@@ -291,6 +314,7 @@ def main():
                        "parallelism": f"dp{world}", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
                        "loss": loss_val},
             "roofline": roofline,
+            "stages": stages,
             "kernel_ms_per_step": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
