@@ -178,10 +178,11 @@ def test_sliding_window_step_matches_reference_loop():
             np.testing.assert_allclose(bbuf.cpu().numpy(), bufs[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
-def test_adaptive_extension_224_matches_oracle():
+@pytest.mark.parametrize("batch,frames", [(2, 4), (1, 8)])      # (1, 8): BASELINE config[0], one 8-frame 224^2 clip
+def test_adaptive_extension_224_matches_oracle(batch, frames):
     """224^2 is not constructible in the reference; the 'adaptive' extension is checked against the oracle twin."""
     from oracle import avse_ref_cpu as orc
-    m = dict(batch=2, frames=4, width=224, fft_len=512, hops_per_frame=8, seed=5)
+    m = dict(batch=batch, frames=frames, width=224, fft_len=512, hops_per_frame=8, seed=5)
     model, twin, (x_a, x_v, y_a, y_v) = _build(m, precise=True, spatial_match="adaptive")
     orc.load_seeded(twin, m["seed"])
     twin.train()
