@@ -173,6 +173,10 @@ int maavss_leaky_bwd(const float* dout, const float* out, float* dz, int64_t n, 
 int maavss_video_phasegram(const float* frames, int64_t batch, int T, int P, int diff, int cumulative, int normalize, float* p_ws,
                            float* absmax_ws, float* out, void* stream);
 
+/* bilinear resize in front of the phasegram (utilities.py:208-209: torchvision resize of a tensor =
+ * torch.nn.functional.interpolate(mode="bilinear", align_corners=False), no antialias): in [n][H][W] -> out [n][h][w]. */
+int maavss_resize_bilinear(const float* in, float* out, int64_t n, int H, int W, int h, int w, void* stream);
+
 /* ---- K12 bidirectional LSTM recurrence (hidden 256, no bias) -- avse_model_final.py:132-133,242 ----
  * gx [B][L][2][4][256] = X.W_ih^T (both directions, gate order i,f,g,o); av [B][L][512]; hp [B][L][2][256];
  * gs [B][L][2][4][256]; cs [B][L][2][256]; bwd: dav [B][L][512] -> dgx (same shape as gx), dc scratch [2][B][256]. */

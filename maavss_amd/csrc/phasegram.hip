@@ -148,3 +148,36 @@ extern "C" int maavss_video_phasegram(const float* frames, int64_t batch, int T,
   }
   return MAAVSS_OK;
 }
+
+// ---- bilinear resize of the attention frames in front of the phasegram (utilities.py:208-209:
+// torchvision.transforms.functional.resize on a tensor = torch.nn.functional.interpolate(mode="bilinear",
+// align_corners=False), no antialiasing in the torchvision of the reference's time).  One thread per output pixel.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                              int H, int W, int h, int w) {
+  const int64_t total = n * h * w;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % w), oy = (int)((i / w) % h);
+    const int64_t img = i / ((int64_t)w * h);
+    float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = in + img * H * W;
+    const float top = p[(int64_t)y0 * W + x0] * (1.f - lx) + p[(int64_t)y0 * W + x1] * lx;
+    const float bot = p[(int64_t)y1 * W + x0] * (1.f - lx) + p[(int64_t)y1 * W + x1] * lx;
+    out[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+
+extern "C" int maavss_resize_bilinear(const float* in, float* out, int64_t n, int H, int W, int h, int w, void* stream) {
+  MAAVSS_CHECK_ARG(in && out && n > 0 && H > 0 && W > 0 && h > 0 && w > 0, "resize_bilinear: bad arguments");
+  const int64_t total = n * h * w;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W, h, w);
+  MAAVSS_LAUNCH_CHECK("resize_bilinear_kernel");
+  return MAAVSS_OK;
+}

@@ -6,19 +6,21 @@ from . import _lib
 
 
 def video_phasegram(frames, resize=None, diff=True, cumulative=True, normalize=True):
-    """frames [B,1,T,H,W] (cuda) -> phasegram [B,1,T,H*W].  Same arguments as the reference.  The reference's optional
-    `resize` goes through torchvision (absent here, and its interpolation is not part of this path): frames must
-    already have the phasegram size (32 or 64 square); a `resize` equal to that size is accepted."""
+    """frames [B,1,T,H,W] (cuda) -> phasegram [B,1,T,h*w].  Same arguments as the reference.  `resize=(h, w)` is the
+    reference's torchvision resize of a tensor, i.e. bilinear interpolation with align_corners=False and no antialiasing
+    (K20's resize kernel); the phasegram itself needs 32x32 or 64x64 frames."""
     _lib.require_cuda(frames)
     if frames.dim() != 5 or frames.shape[1] != 1:
         raise ValueError(f"expected attention frames [B,1,T,H,W], got {tuple(frames.shape)}")
     b, _, t, h, w = frames.shape
-    if resize is not None and tuple(resize) != (h, w):
-        raise NotImplementedError(f"resize {tuple(resize)} != frame size {(h, w)}: resize the attention frames before the call "
-                                  "(the reference uses torchvision.transforms.functional.resize, utilities.py:209)")
-    if h != w or h not in (32, 64):
-        raise ValueError(f"phasegram frames must be 32x32 or 64x64, got {h}x{w}")
     x = frames.contiguous().float()
+    if resize is not None and tuple(resize) != (h, w):
+        rh, rw = int(resize[0]), int(resize[1])
+        small = torch.empty(b, 1, t, rh, rw, device=x.device, dtype=torch.float32)
+        _lib.call("maavss_resize_bilinear", _lib.ptr(x), _lib.ptr(small), b * t, h, w, rh, rw, _lib.stream_ptr())
+        x, h, w = small, rh, rw
+    if h != w or h not in (32, 64):
+        raise ValueError(f"phasegram frames must be 32x32 or 64x64 (after resize), got {h}x{w}")
     out = torch.empty(b, 1, t, h * w, device=x.device, dtype=torch.float32)
     ws = torch.empty(b, t, h * w, device=x.device, dtype=torch.float32)
     amax = torch.empty(1, device=x.device, dtype=torch.float32)

@@ -200,3 +200,21 @@ def test_video_phasegram_matches_oracle(golden_dir, p, diff, cumulative, normali
         z = np.load(os.path.join(golden_dir, "avfm_A.npz"), allow_pickle=False)
         np.testing.assert_array_equal(attn.flatten()[::97].numpy(), z["attn_sample"])
         np.testing.assert_allclose(got.flatten()[::13].cpu().numpy(), z["pgram_sample"], rtol=0, atol=2e-5)
+
+
+def test_video_phasegram_with_resize():
+    """resize=(p, p) as train_av_net.py:122-125 calls it: torchvision's tensor resize = F.interpolate(bilinear,
+    align_corners=False); checked against torch on the CPU, then the phasegram of the resized frames against the oracle."""
+    import maavss_amd
+    from maavss_amd import _lib
+    from oracle import avfm_ref_cpu as avfm
+    g = torch.Generator().manual_seed(3)
+    attn = torch.rand(2, 1, 4, 224, 224, generator=g)
+    small_ref = F.interpolate(attn[:, 0], size=(64, 64), mode="bilinear", align_corners=False).unsqueeze(1)
+    xc = attn.cuda()
+    small = torch.empty(2, 1, 4, 64, 64, device="cuda")
+    _lib.call("maavss_resize_bilinear", _lib.ptr(xc), _lib.ptr(small), 8, 224, 224, 64, 64, _lib.stream_ptr())
+    np.testing.assert_allclose(small.cpu().numpy(), small_ref.numpy(), rtol=0, atol=2e-6)
+    got = maavss_amd.video_phasegram(xc, resize=(64, 64))
+    want = avfm.video_phasegram_ref(small_ref)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=5e-5 * float(want.abs().max()))
