@@ -11,7 +11,11 @@
 // was requested twice as two 64-B halves).  Hence:
 //   * BK = 64 bf16 = one full 128-B line per row and staging instruction; 256x128 tile = 85 FLOP per staged byte;
 //   * operand tiles go global -> LDS directly (global_load_lds, 16 B per lane) into a 3-slot ring (144 KiB, one
-//     workgroup of 8 waves per CU); two K-steps stay in flight across a raw s_barrier behind a counted vmcnt;
+//     workgroup per CU); two K-steps stay in flight across a raw s_barrier behind a counted vmcnt;
+//   * the DMA instructions are issued by FOUR DEDICATED LOADER WAVES (waves 8-11: 12 one-KiB pieces each per K-step),
+//     not by the eight MFMA waves: one global_load_lds costs its wave 60-300 issue cycles ("What the
+//     K = 384 GEMM taught"), which with the stream spread over the MFMA waves came out of the MFMA issue slots;
+//     the loaders execute exactly the barrier sequence of the MFMA waves;
 //   * the workgroups are PERSISTENT (one per CU) and the DMA stream runs across tile boundaries: while a tile's
 //     epilogue runs (staged through the ring slot that just became free), the first two K-steps of the next
 //     tile are already in flight, so the per-tile prologue latency -- the dominant cost at K = 384 -- is hidden;
@@ -34,9 +38,12 @@
 #define VG_BN 128
 #define VG_BK 64
 #define VG_STAGES 3
-#define VG_THREADS 512
+#define VG_MMA_WAVES 8
+#define VG_LOADERS 4
+#define VG_THREADS 768
+#define VG_MMA_THREADS 512
 #define VG_STAGE_ELEMS ((VG_BM + VG_BN) * VG_BK)  // A tile + B tile, bf16 elements (48 KiB)
-#define VG_LOADS 6                                 // global_load_lds per wave per stage (4 A + 2 B)
+#define VG_LOADS 12                                // global_load_lds per LOADER wave per stage (8 A + 4 B)
 
 struct VGemmArgs {
   const bf16_t* A;
@@ -67,7 +74,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
+__global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [3 slots][A 256x64 | B 128x64] bf16 = 144 KiB
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -86,24 +93,25 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
   if (my_count == 0) return;
   const int total_steps = my_count * nk;  // virtual K-step stream across this block's tiles
 
-  // ---- staging stream state (runs two K-steps ahead of the MFMAs, across tile boundaries)
-  const int srow = lane >> 3, sslot = lane & 7;
-  const bf16_t* asrc[4];
-  const bf16_t* bsrc[2];
+  // ---- staging stream (loader waves only; runs two K-steps ahead of the MFMAs, across tile boundaries).
+  // Loader lw stages A rows lw*64 .. +63 (8 pieces of 8 rows) and W rows lw*32 .. +31 (4 pieces).
+  const int srow = lane >> 3, sslot = lane & 7, lw = wv - VG_MMA_WAVES;
+  const bf16_t* asrc[8];
+  const bf16_t* bsrc[4];
   int s_tile = -1;
   auto set_stage_tile = [&](int ti) {
     const int id = my_first + ti * per_xcd;
     const int m0 = (id / g.tiles_n) * VG_BM, n0 = (id % g.tiles_n) * VG_BN;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = wv * 32 + i * 8 + srow;
+    for (int i = 0; i < 8; ++i) {
+      const int r = lw * 64 + i * 8 + srow;
       int ar = m0 + r;
       ar = ar < g.M ? ar : g.M - 1;
       asrc[i] = g.A + (int64_t)ar * g.lda + ((sslot ^ (r & 7)) * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = wv * 16 + i * 8 + srow;
+    for (int i = 0; i < 4; ++i) {
+      const int r = lw * 32 + i * 8 + srow;
       bsrc[i] = g.W + (int64_t)(n0 + r) * g.K + ((sslot ^ (r & 7)) * 8);
     }
     s_tile = ti;
@@ -114,10 +122,43 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
     bf16_t* la = lds + (v % VG_STAGES) * VG_STAGE_ELEMS;
     bf16_t* lb = la + VG_BM * VG_BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(asrc[i] + kt * VG_BK, la + (wv * 32 + i * 8) * VG_BK + lane * 8);
+    for (int i = 0; i < 8; ++i) glds16(asrc[i] + kt * VG_BK, la + (lw * 64 + i * 8) * VG_BK + lane * 8);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(bsrc[i] + kt * VG_BK, lb + (wv * 16 + i * 8) * VG_BK + lane * 8);
+    for (int i = 0; i < 4; ++i) glds16(bsrc[i] + kt * VG_BK, lb + (lw * 32 + i * 8) * VG_BK + lane * 8);
   };
+  // barriers of one tile epilogue (the loaders execute them too)
+  constexpr int EPI_BARRIERS = (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) ? 3 : 7;
+
+  if (wv >= VG_MMA_WAVES) {
+    // ================= loader waves: the MFMA waves' barrier sequence with the DMA issue in between =================
+    stage(0);
+    if (total_steps > 1) stage(1);
+    if (total_steps > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step 0 landed (this wave's part)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int v = 0;
+    for (int ti = 0; ti < my_count; ++ti) {
+      for (int kt = 0; kt < nk; ++kt, ++v) {
+        // slot of step v-1 is free (all fragment reads of step v-1 retired before the last barrier) -> refill it
+        const bool issued = v + 2 < total_steps;
+        if (issued) stage(v + 2);
+        if (kt + 1 < nk) {
+          // make step v+1 visible: counted vmcnt (the step issued above may stay in flight) + barrier
+          if (issued) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      __builtin_amdgcn_s_barrier();   // tile done
+#pragma unroll
+      for (int b = 0; b < EPI_BARRIERS; ++b) __builtin_amdgcn_s_barrier();
+      if (ti + 1 < my_count) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's first two steps have landed
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
 
   int rowa[4], rowb[4];
 #pragma unroll
@@ -144,12 +185,9 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
   __builtin_amdgcn_sched_barrier(0);         \
   asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]))
 
-  stage(0);
-  if (total_steps > 1) stage(1);
+  // ================= MFMA waves =================
   bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-  if (total_steps > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step 0 landed (this wave's part)
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();   // step 0 landed (loaders waited for it)
   load_frags(0, 0, fa0, fb0);
   VG_USE_FRAGS(fa0, fb0);
 
@@ -161,17 +199,11 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk; ++kt, ++v) {
       const int slot = v % VG_STAGES;
-      // slot of step v-1 is free (all fragment reads of step v-1 retired before the last barrier) -> refill it
-      const bool issued = v + 2 < total_steps;
-      if (issued) stage(v + 2);
       load_frags(slot, 1, fa1, fb1);   // sub-step 1 reads go out first, sub-step 0 MFMAs run underneath
       mfmas(fa0, fb0);
       VG_USE_FRAGS(fa1, fb1);
       if (kt + 1 < nk) {
-        // make step v+1 visible: counted vmcnt (the step issued above may stay in flight) + barrier
-        if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();   // step v+1 visible (the loaders waited for it), slot v-1 handed back
         load_frags((v + 1) % VG_STAGES, 0, fa0, fb0);
       }
       mfmas(fa1, fb1);
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
           __syncthreads();
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const int q = it * VG_THREADS + tid, row = q >> 4, c16 = q & 15;
+            const int q = it * VG_MMA_THREADS + tid, row = q >> 4, c16 = q & 15;
             const int m = m0 + pass * 128 + row;
             if (m < g.M)
               *reinterpret_cast<uint4*>(C + (int64_t)m * g.ldc + n0 + c16 * 8) = *reinterpret_cast<const uint4*>(cs + row * LDC + c16 * 8);
@@ -222,9 +254,44 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
         constexpr int LDF = 132;  // [64][132] f32 = 33 KiB per pass
         float* cf = reinterpret_cast<float*>(ebuf);
         float* C = reinterpret_cast<float*>(g.C);
+        // The residual (or row-table) values are requested AHEAD of their use -- passes 0-1 up front, pass 2 / 3 as pass
+        // 0 / 1 release their registers (8 + 4 float4 per thread in flight, in the registers the operand fragments just
+        // vacated; the budget is 168 VGPRs at 12 waves per CU) -- so their HBM latency is paid about once per tile
+        // instead of once per pass (one workgroup per CU: nothing else would cover it; it was 240 of 710 us on fc2;
+        // requesting them under the tile's last MFMAs as well spills).  The barriers here are raw s_barriers behind an
+        // LDS-only wait: __syncthreads() would also drain vmcnt, i.e. wait for these loads and the previous stores.
+        const int c4 = (tid & 31) * 4, rbase = tid >> 5;
+        // addresses: a buffer descriptor on the tile (wave-uniform, SGPRs) + one 32-bit lane offset (the 16-row step is
+        // added at each use: the range check covers the VGPR offset, not an SGPR one), so the sixteen requests hold no
+        // address registers; the descriptor ends after the last real row: rows past M read 0 and are not written.
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        unsigned voff = (unsigned)(rbase * g.ldc + c4) * 4u;
+        asm volatile("" : "+v"(voff));   // per tile: hipcc otherwise hoists the sixteen offsets out of the tile loop and spills them
+        const unsigned cstep = 16u * (unsigned)g.ldc * 4u;
+        const int64_t rem = ((int64_t)(g.M - m0 - 1) * g.ldc + VG_BN) * 4;
+        const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+            C + (int64_t)m0 * g.ldc + n0, 0, (int)(rem < 0xFFFFFFF0LL ? rem : 0xFFFFFFF0LL), 0x00020000);
+        float4 addv[16];
+        auto request = [&](int e) __attribute__((always_inline)) {   // e = pass * 4 + it: row pass*64 + it*16 + (tid >> 5)
+          if constexpr (EPI == EPI_F32_BIAS_RESID) {
+            addv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(crsrc, voff + e * cstep, 0, 0));
+          } else {
+            const int m = m0 + e * 16 + rbase;
+            addv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < g.M) addv[e] = *reinterpret_cast<const float4*>(g.table + (int64_t)(m % g.period) * g.N + n0 + c4);
+          }
+        };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) request(e);
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI == EPI_F32_BIAS_RESID) bb = *reinterpret_cast<const float4*>(g.bias + n0 + c4);
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          if (pass) __syncthreads();
+          if (pass) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          }
           if (wm == pass) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -233,30 +300,33 @@ __global__ __launch_bounds__(VG_THREADS, 2) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cf[(i * 16 + gq * 4 + r) * LDF + wn * 64 + j * 16 + l16] = acc[i][j][r];
           }
-          __syncthreads();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" : "+v"(voff) : : "memory");
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const int q = it * VG_THREADS + tid, row = q >> 5, c4 = (q & 31) * 4;
-            const int m = m0 + pass * 64 + row;
-            if (m < g.M) {
-              const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
-              float4* cp = reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n0 + c4);
-              float4 add;
-              if constexpr (EPI == EPI_F32_BIAS_RESID) {
-                const float4 res = *cp, bb = *reinterpret_cast<const float4*>(g.bias + n0 + c4);
-                add = make_float4(res.x + bb.x, res.y + bb.y, res.z + bb.z, res.w + bb.w);
-              } else {
-                add = *reinterpret_cast<const float4*>(g.table + (int64_t)(m % g.period) * g.N + n0 + c4);
-              }
-              *cp = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
-            }
+            const int row = it * 16 + rbase;
+            const float4 a = *reinterpret_cast<const float4*>(cf + row * LDF + c4);
+            const float4 res = addv[pass * 4 + it];
+            float4 add;
+            if constexpr (EPI == EPI_F32_BIAS_RESID) add = make_float4(res.x + bb.x, res.y + bb.y, res.z + bb.z, res.w + bb.w);
+            else add = res;
+            const float4 o4 = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o4), crsrc, voff + (pass * 4 + it) * cstep, 0, 0);
+          }
+          if (pass < 2) {
+#pragma unroll
+            for (int e = 8 + 4 * pass; e < 12 + 4 * pass; ++e) request(e);
           }
         }
       }
     }
     if (ti + 1 < my_count) {
-      // everything issued so far (the next tile's first two steps and this tile's stores) has landed / drained
-      __syncthreads();   // = s_waitcnt vmcnt(0) lgkmcnt(0) + barrier: the staging slot is free again, step v is visible
+      // The staging slot is free again (every wave's LDS reads are done) and the loaders have waited for the next tile's
+      // first two steps; this tile's global stores keep draining under the next tile's MFMAs (no vmcnt wait here).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       load_frags(v % VG_STAGES, 0, fa0, fb0);
       VG_USE_FRAGS(fa0, fb0);
     }
