@@ -11,11 +11,16 @@
 //         slot (g, e) is assigned to key 32*ks + 16*(e>>2) + 4*g + (e&3), and V^T fragments are read with the same
 //         assignment by ds_read_b64_tr_b16) -- P never goes through LDS.
 // K/V tiles are double-buffered in LDS (K XOR-swizzled per 16-B chunk for ds_read_b128, V per 32-B granule for
-// the transposed reads); the next tile's global loads are issued before the MFMAs and written after them.
+// the transposed reads: both conflict-free for the hardware's lane groups); the next tile's global loads (wave-uniform
+// frame base + one 32-bit lane offset, clamped to the last row instead of predicated) are issued before the MFMAs and
+// written after them; the last key tile, the only one with padded keys, is peeled off the loop.  The row maximum is
+// taken per LANE (v_max3 chain); the exchange across a query's four lanes only runs when m_run has to move.  The two
+// MFMA phases run at s_setprio 1 so that the other resident waves' softmax VALU fills their issue gaps.
 // qkv is the fused projection output [rows][1152] bf16 with q pre-scaled by log2(e)/8 in the GEMM epilogue
 // (softmax runs on exp2); out is [rows][384] bf16 with heads concatenated.
 // vit_cls_attn_kernel: last block only -- the CLS query against all keys, softmax over N tokens, the CLS
 // column dropped (video_attention.py:56): att [frames][6][N-1] f32.
+#include <type_traits>
 #include "mma.h"
 
 #define ATT_D 64
@@ -25,7 +30,7 @@
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vit_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok,
                                                        int ld_qkv, int ld_out, int dim, int heads, int qblocks,
                                                        int ngroups) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][ATT_KT * ATT_D];
@@ -65,16 +70,24 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
 
   // staging map: thread -> (key = idx>>3, 16-B chunk c = idx&7) for idx = tid and tid + 256
   uint4 kreg[2], vreg[2];
-  auto load_tile = [&](int kv0) {
+  // K / V addresses: a wave-uniform frame base (SGPRs) plus a 32-bit byte offset per thread that advances by one key
+  // tile per iteration (one frame's qkv is ntok * ld_qkv * 2 bytes, far below 4 GB)
+  const char* kframe = reinterpret_cast<const char*>(kbase + row0 * ld_qkv);
+  const char* vframe = reinterpret_cast<const char*>(vbase + row0 * ld_qkv);
+  // Rows past the sequence end are read from the last real row instead (finite values; their scores are masked and
+  // their probabilities are exactly 0), so the loads need no predicate and the registers no zero fill.
+  unsigned ldoff[2], ldmax;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) ldoff[it] = (unsigned)((it * 32 + (tid >> 3)) * ld_qkv + (tid & 7) * 8) * 2u;
+  ldmax = (unsigned)((ntok - 1) * ld_qkv + (tid & 7) * 8) * 2u;
+  const unsigned tile_step = (unsigned)(ATT_KT * ld_qkv) * 2u;
+  auto load_tile = [&]() {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int idx = it * 256 + tid, key = idx >> 3, c = idx & 7;
-      kreg[it] = make_uint4(0, 0, 0, 0);
-      vreg[it] = make_uint4(0, 0, 0, 0);
-      if (kv0 + key < ntok) {
-        kreg[it] = *reinterpret_cast<const uint4*>(kbase + (row0 + kv0 + key) * ld_qkv + c * 8);
-        vreg[it] = *reinterpret_cast<const uint4*>(vbase + (row0 + kv0 + key) * ld_qkv + c * 8);
-      }
+      const unsigned off = ldoff[it] < ldmax ? ldoff[it] : ldmax;
+      kreg[it] = *reinterpret_cast<const uint4*>(kframe + off);
+      vreg[it] = *reinterpret_cast<const uint4*>(vframe + off);
+      ldoff[it] += tile_step;
     }
   };
   auto store_tile = [&](int buf) {
@@ -87,16 +100,14 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
   };
 
   const int ntiles = (ntok + ATT_KT - 1) / ATT_KT;
-  load_tile(0);
+  load_tile();
   store_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Q fragments too, so that no wait on them lands inside the loop
   __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // one key tile of this wave's 32 queries; `last_c` = the final tile (the only one that can hold padded keys)
+  auto tile = [&](int kt, auto last_c) __attribute__((always_inline)) {
     const int buf = kt & 1, kv0 = kt * ATT_KT;
-    if (kt + 1 < ntiles) load_tile(kv0 + ATT_KT);
-    // A wave whose 32 query rows all lie past the sequence end (ntok = 785: three of the four waves of the last query
-    // block, 11 % of all waves) only helps staging K / V: its MFMA and softmax issue slots go to the other workgroups
-    // resident on the SIMD.
-    if (wave_active) {
+    __builtin_amdgcn_s_setprio(1);
     // ---- S^T = K Q^T : s[t][nt][r] = score(key 16 nt + 4 gq + r, query t*16 + l16)
     // The running row maximum goes in as the MFMA's C operand (s' = score - m_run), so no subtraction pass.
     f32x4 s[2][4];
@@ -112,13 +123,14 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
         Mma<MODE_BF16>::mma(s[1][nt], fk, fq[1][ks]);
       }
     }
-    if (kv0 + ATT_KT > ntok) {  // last, partial tile: mask the padded keys
+    if (decltype(last_c)::value && kv0 + ATT_KT > ntok) {  // last, partial tile: mask the padded keys
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kv0 + nt * 16 + gq * 4 + r >= ntok) { s[0][nt][r] = -1e30f; s[1][nt][r] = -1e30f; }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- online softmax (base 2), query on the lane
     // Deferred rescale: m_run only moves when the tile maximum exceeds it by more than ATT_THR (then P <= 2^ATT_THR,
     // harmless in f32 / bf16); the O / l rescale is a rare wave-uniform branch instead of 32 multiplies per tile.
@@ -126,16 +138,24 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
     float mx[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      // 16 scores per lane and query: eight v_max3_f32 (three inputs per instruction) instead of fifteen v_max_f32
-      auto max3 = [](float a, float b, float c) __attribute__((always_inline)) { return fmaxf(fmaxf(a, b), c); };
+      // 16 scores per lane and query: eight v_max3_f32 (three inputs per instruction; written as asm so that hipcc does
+      // not put a canonicalising v_max in front of every MFMA output)
+      auto max3 = [](float a, float b, float c) __attribute__((always_inline)) {
+        float d;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+      };
       const float a0 = max3(s[t][0][0], s[t][0][1], s[t][0][2]), a1 = max3(s[t][0][3], s[t][1][0], s[t][1][1]);
       const float a2 = max3(s[t][1][2], s[t][1][3], s[t][2][0]), a3 = max3(s[t][2][1], s[t][2][2], s[t][2][3]);
       const float a4 = max3(s[t][3][0], s[t][3][1], s[t][3][2]);
-      float m = max3(max3(a0, a1, a2), max3(a3, a4, s[t][3][3]), -3.0e38f);
-      mx[t] = rows4_max(m);   // max over the four lanes (gq) of a query: lane-swap instructions, no LDS crossbar
+      mx[t] = max3(max3(a0, a1, a2), a3, max3(a4, s[t][3][3], s[t][3][3]));   // this lane's 16 keys only
     }
     const bool first = kt == 0;
+    // The maximum over a query's four lanes is only needed when m_run moves: some lane exceeding the threshold is the
+    // same condition as some query exceeding it, so the steady state pays no cross-lane exchange at all.
     if (__any(first || mx[0] > ATT_THR || mx[1] > ATT_THR)) {
+      mx[0] = rows4_max(mx[0]);
+      mx[1] = rows4_max(mx[1]);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const float delta = (first || mx[t] > ATT_THR) ? mx[t] : 0.f;   // first tile: rebase in either direction
@@ -172,6 +192,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
         fp[t][ks] = __builtin_bit_cast(bf16x8, u);
       }
     }
+    __builtin_amdgcn_s_setprio(1);
     // ---- O^T += V^T P^T : o[t][dt][r] = O(query t*16 + l16, d = 16 dt + 4 gq + r)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -188,10 +209,25 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* __restrict_
         Mma<MODE_BF16>::mma(o[0][dt], fv, fp[0][ks]);
         Mma<MODE_BF16>::mma(o[1][dt], fv, fp[1][ks]);
       }
-    }   // wave_active
-    if (kt + 1 < ntiles) store_tile(buf ^ 1);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // A wave whose 32 query rows all lie past the sequence end (ntok = 785: three of the four waves of the last query
+  // block, 11 % of all waves) only helps staging K / V: its MFMA and softmax issue slots go to the other workgroups
+  // resident on the SIMD.
+  for (int kt = 0; kt < ntiles - 1; ++kt) {
+    load_tile();
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: their latency is covered by the tile's MFMAs
+    if (wave_active) tile(kt, std::false_type{});
+    // the LDS writes stay below the tile's MFMAs (hipcc otherwise merges them into the load block above)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      asm volatile("" : "+v"(kreg[it].x), "+v"(kreg[it].y), "+v"(kreg[it].z), "+v"(kreg[it].w));
+      asm volatile("" : "+v"(vreg[it].x), "+v"(vreg[it].y), "+v"(vreg[it].z), "+v"(vreg[it].w));
+    }
+    store_tile((kt & 1) ^ 1);
     __syncthreads();
   }
+  if (wave_active) tile(ntiles - 1, std::true_type{});
   // ---- normalise and store: lane holds d = 16 dt + 4 gq + (0..3) of its query
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
