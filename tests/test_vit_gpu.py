@@ -129,6 +129,30 @@ def test_vit_attention_and_cls(ntok, frames):
     np.testing.assert_allclose(att.cpu().numpy(), p[:, :, 0, 1:].numpy(), rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("ntok,frames,ramp", [(1, 2, 0.0), (64, 2, 0.0), (129, 1, 0.0), (785, 1, 6.0), (300, 2, -6.0)])
+def test_vit_attention_edges_and_running_maximum(ntok, frames, ramp):
+    """Sequence lengths at the key-tile edges (1, exactly one tile, one key into the third tile) and score ramps along the
+    keys: with ramp > 0 every key tile raises the row maximum far beyond the deferred-rescale threshold (the O / l rescale
+    path runs tile after tile), with ramp < 0 the first tile holds the maximum and later tiles underflow to exact zeros."""
+    rows = frames * ntok
+    qkv = bf(rnd(rows, 1152, seed=5, scale=1.0))
+    qkv[:, :384] *= 0.125 * 3 * 1.4426950408889634
+    if ramp:
+        scale = torch.linspace(1.0, abs(ramp), ntok).repeat(frames)
+        if ramp < 0:
+            scale = scale.flip(0)
+        qkv[:, 384:768] = bf(qkv[:, 384:768].float() * scale[:, None])      # |k| grows (or shrinks) along the sequence
+    out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
+    qc = qkv.cuda()
+    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
+    q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.double().split(384, 1)]
+    p = ((q @ k.transpose(-1, -2)) * 0.6931471805599453).softmax(-1)
+    want = (p @ v).transpose(1, 2).reshape(rows, 384)
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-2, atol=1.2e-2)
+
+
 def test_attn_maps_postprocess():
     from oracle import vit_ref_cpu as vref
     f, hp, wp = 6, 5, 4
