@@ -182,14 +182,17 @@ class VideoAttention:
         qs = 0.125 * 1.4426950408889634          # q *= log2(e)/sqrt(64): the attention kernels run softmax on exp2
         for i in range(DEPTH):
             b = wts[i]
+            # the last block only feeds the CLS-row attention (get_last_selfattention): q and k, not v -- the weight rows
+            # are [q; k; v], so N = 2 DIM computes exactly those two thirds into the same [rows, 3 DIM] buffer
+            nqkv = 2 * DIM if i == DEPTH - 1 else 3 * DIM
             if self.fused_panel_gemm:
                 # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
-                     ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, 3 * DIM, EPI_BF16_BIAS, DIM, qs, st)
+                     ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv, EPI_BF16_BIAS, DIM, qs, st)
             else:
                 call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, st)
                 call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["qkv_w"]), ptr(b["qkv_b"]), None, 0, ptr(qkv), 3 * DIM, rows,
-                     3 * DIM, DIM, EPI_BF16_BIAS, DIM, qs, st)
+                     nqkv, DIM, EPI_BF16_BIAS, DIM, qs, st)
             if i == DEPTH - 1:
                 break
             call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, st)
