@@ -38,30 +38,61 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
 
   const int tiles_total = BT * tiles_x * tiles_y;
   const int tile_beg = chunk * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
-  for (int tile = tile_beg; tile < tile_end; ++tile) {
+  // Staging is a REGISTER PREFETCH: all of a tile's global loads (NX + ND float4 per thread) are issued before the
+  // previous tile's MFMAs and converted / written to LDS after them.  With one load in flight per thread (a plain
+  // load -> convert -> store loop) the 13 dependent round trips per tile were 52 % of this kernel's time (scratch build
+  // without staging: 2.2 vs 3.3 ms per step over the wgrad launches); one 512-thread workgroup per CU leaves 256
+  // VGPRs per lane, so the 56 - 60 staging registers are free.
+  constexpr int XV = KDN * 400 * (CI / 4), DV = 256 * (CO / 4);   // float4s per tile
+  constexpr int NX = (XV + 511) / 512, ND = (DV + 511) / 512;
+  float4 xr[NX], dr[ND];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y);
     const int t = bt % T, x0 = tx * 16, y0 = ty * 16;
-    __syncthreads();
-    for (int i = tid; i < KDN * 400 * (CI / 4); i += 512) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + j * 512;
       const int c4 = (i % (CI / 4)) * 4, pos = (i / (CI / 4)) % 400, kdl = i / ((CI / 4) * 400);
       const int r = pos / 20, c = pos % 20;
       const int tt = t + kd0 + kdl - 1, iy = y0 + r - pad, ix = x0 + c - pad;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CI + c4);
-      E* d = xs + (kdl * 400 + pos) * CI + c4;
-      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < XV && tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        xr[j] = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CI + c4);
     }
     const float* dp = dy + (int64_t)bt * Ho * Wo * CO;
-    for (int i = tid; i < 256 * (CO / 4); i += 512) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int i = tid + j * 512;
       const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
       const int oy = y0 + pos / 16, ox = x0 + pos % 16;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
-      E* d = ds + pos * CO + c4;
-      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      dr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < DV && oy < Ho && ox < Wo) dr[j] = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
     }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + j * 512;
+      if (i < XV) {
+        E* d = xs + (int64_t)i * 4;   // [kdl][pos][CI]: the float4 index is the element index / 4
+        d[0] = M::cvt(xr[j].x); d[1] = M::cvt(xr[j].y); d[2] = M::cvt(xr[j].z); d[3] = M::cvt(xr[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int i = tid + j * 512;
+      if (i < DV) {
+        E* d = ds + (int64_t)i * 4;   // [pos][CO]
+        d[0] = M::cvt(dr[j].x); d[1] = M::cvt(dr[j].y); d[2] = M::cvt(dr[j].z); d[3] = M::cvt(dr[j].w);
+      }
+    }
+  };
+  if (tile_beg < tile_end) fetch(tile_beg);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    __syncthreads();   // the previous tile's fragment reads are done
+    stash();
     __syncthreads();
+    if (tile + 1 < tile_end) fetch(tile + 1);
 #pragma unroll 1
     for (int ks = 0; ks < 8; ++ks) {
       // K step = output rows 2ks, 2ks+1; k = 0..31 -> (row 2ks + k/16, col k%16)
