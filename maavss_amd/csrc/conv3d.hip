@@ -98,20 +98,60 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kd = 0; kd < 3; ++kd) {
-    const int tt = t + kd - 1;
-    if (tt < 0 || tt >= T) continue;  // block-uniform
-    __syncthreads();
-    // ---- stage the 20x20xCIN halo of frame tt (zero-filled outside the image)
+  // ---- halo staging.  C_in = 64: the 25 float4 of a thread's share of the NEXT frame's halo are requested before this
+  // frame's MFMAs and converted / written to LDS after them (register prefetch).  With a plain load -> convert -> store
+  // loop one load is in flight per thread: 25 dependent round trips per frame, and these variants run only two
+  // workgroups per CU (60 - 70 KB of LDS each), too few to cover that; the same LDS limit leaves 256 VGPRs per lane,
+  // so the 100 staging registers are free.  (Scratch build without the halo loads: igemm 4.3 -> 2.9 ms per step.)
+  // The smaller C_in variants run 3 - 5 workgroups per CU and keep the plain loop (batched loads cost them occupancy).
+  constexpr int HV = 400 * (CIN / 4), NV = (HV + 255) / 256;
+  constexpr bool PREFETCH = CIN >= 64;
+  float4 hv[PREFETCH ? NV : 1];
+  auto fetch = [&](int kd) __attribute__((always_inline)) {
     const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
-    for (int i = tid; i < 400 * (CIN / 4); i += 256) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));   // the index arithmetic is redone per call: hoisted out of the kd loop it costs 100+ registers
+#pragma unroll
+    for (int j = 0; j < (PREFETCH ? NV : 1); ++j) {
+      const int i = tv + j * 256;
       const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
       const int r = pos / 20, c = pos % 20;
       const int iy = y0 + r - pad, ix = x0 + c - pad;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
-      E* d = halo + (pos * NCH + swz<RBH>(c, c4 / EPC)) * EPC + (c4 % EPC);
-      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < HV && iy >= 0 && iy < H && ix >= 0 && ix < W) hv[j] = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+#pragma unroll
+    for (int j = 0; j < (PREFETCH ? NV : 1); ++j) {
+      const int i = tv + j * 256;
+      if (i < HV) {
+        const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4, c = pos % 20;
+        E* d = halo + (pos * NCH + swz<RBH>(c, c4 / EPC)) * EPC + (c4 % EPC);
+        d[0] = M::cvt(hv[j].x); d[1] = M::cvt(hv[j].y); d[2] = M::cvt(hv[j].z); d[3] = M::cvt(hv[j].w);
+      }
+    }
+  };
+  const int kd_lo = t == 0 ? 1 : 0, kd_hi = t == T - 1 ? 1 : 2;   // frames t + kd - 1 inside the clip (block-uniform)
+  if constexpr (PREFETCH) fetch(kd_lo);
+  for (int kd = kd_lo; kd <= kd_hi; ++kd) {
+    __syncthreads();
+    // ---- stage the 20x20xCIN halo of frame t + kd - 1 (zero-filled outside the image)
+    if constexpr (PREFETCH) {
+      stash();
+    } else {
+      const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
+      for (int i = tid; i < HV; i += 256) {
+        const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+        const int r = pos / 20, c = pos % 20;
+        const int iy = y0 + r - pad, ix = x0 + c - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
+        E* d = halo + (pos * NCH + swz<RBH>(c, c4 / EPC)) * EPC + (c4 % EPC);
+        d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      }
     }
     // ---- weight chunk 0 of this kd
     const E* wk = wt + (int64_t)kd * COUT * KP;
@@ -121,6 +161,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
           *reinterpret_cast<const uint4*>(wk + (int64_t)n * KP + c * EPC);
     }
     __syncthreads();
+    if constexpr (PREFETCH) {
+      if (kd < kd_hi) fetch(kd + 1);
+    }
     for (int ch = 0; ch < NCHUNK; ++ch) {
       constexpr int WV = (COUT * NCW + 255) / 256;
       uint4 wreg[WV];
