@@ -59,6 +59,28 @@ def test_vit_gemm_epilogues(m, n, k):
     np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("epi", [2, 3])
+def test_vit_gemm_f32_epilogue_stays_inside_its_rows_and_columns(epi):
+    """The f32 epilogues address C through a range-checked buffer descriptor that ends after row M-1: rows past M (the
+    last 256-row tile is ragged) and the columns between N and ldc must keep their contents."""
+    m, n, k, ldc, pad_rows = 130, 384, 192, 384 + 128, 200
+    a, w, bias = bf(rnd(m, k, seed=1)), bf(rnd(n, k, seed=2, scale=k ** -0.5)), rnd(n, seed=3, scale=0.1)
+    table = rnd(13, n, seed=5)
+    sentinel = 12345.0
+    x = torch.full((m + pad_rows, ldc), sentinel)
+    res = rnd(m, n, seed=4)
+    x[:m, :n] = res
+    xc, ac, wc, bc, tc = x.cuda(), a.cuda(), w.cuda(), bias.cuda(), table.cuda()
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr() if epi == 2 else None, tc.data_ptr() if epi == 3 else None,
+          13 if epi == 3 else 0, xc.data_ptr(), ldc, m, n, k, epi, 0, 1.0, _st())
+    got = xc.cpu()
+    z = a.float() @ w.float().t()
+    want = res + z + bias if epi == 2 else z + table[torch.arange(m) % 13]
+    np.testing.assert_allclose(got[:m, :n].numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
+    assert (got[m:] == sentinel).all(), "rows past M were written"
+    assert (got[:m, n:] == sentinel).all(), "columns past N were written"
+
+
 @pytest.mark.parametrize("m,n", [(1000, 1152), (785 * 2 + 3, 1536), (130, 384)])
 def test_vit_panel_gemm_fused_layernorm(m, n):
     """LN + GEMM panel kernel (K = 384) against torch: LayerNorm in f32, operands rounded to bf16, f32 accumulate."""
