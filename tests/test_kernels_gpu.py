@@ -78,6 +78,7 @@ def from_cl(x):
     (32, 64, 2, 2, 2, 16, 16),
     (64, 64, 2, 1, 4, 28, 28),
     (64, 16, 3, 2, 3, 10, 10),
+    (64, 64, 2, 2, 1, 16, 16),     # T = 1: only the centre kd plane touches a real frame (prefetch range kd_lo = kd_hi)
 ])
 def test_conv3d_igemm_fwd_dgrad_wgrad(ci, co, pad, b, t, h, w, precise):
     from maavss_amd import ops
