@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--precise", action="store_true", help="exact-f32 MFMA in the fusion network (parity mode)")
     ap.add_argument("--verbose", action="store_true", help="per-shape kernel table on stderr")
     ap.add_argument("--vit-chunk", type=int, default=0, help="frames per ViT launch group (0 = library default)")
+    ap.add_argument("--sync-bn", action="store_true", help="global-batch BatchNorm statistics over the ranks (N > 1)")
     return ap.parse_args()
 
 
@@ -64,7 +65,9 @@ def synthetic_inputs(torch, batch, frames, width, length, seed, device):
 
 def cpu_baseline(args):
     """The CPU oracle (validated restatement of the reference path, oracle/) on the host cores: one clip
-    end to end = ViT attention frames for T frames + STFT + one AVSE train step (fwd+bwd+Adam)."""
+    end to end = ViT attention frames for its T frames + STFT + one AVSE train step (fwd+bwd+Adam).
+    SURVEY.md 8(d): 2 warm-ups, then the median of >= 5 timed repetitions (bounded to ~25 s of CPU work)."""
+    import statistics
     import torch
     from oracle import avse_ref_cpu as orc, stft_ref_cpu as sref, vit_ref_cpu as vref
     cores = host_cores()
@@ -77,26 +80,13 @@ def cpu_baseline(args):
     model = orc.AVFusionFramesRef([b, 2, t_a, n_bins], [b, 1, t, w, w], hpf, spatial_match="adaptive")
     opt = torch.optim.Adam(model.parameters(), lr=1e-5)
     model.train()
-    vit_frames = min(4, t)
-    frames = vref.synthetic_frames(vit_frames, w, 1)
+    frames = vref.synthetic_frames(t, w, 1)
     audio = sref.synthetic_audio(b, length, 2)
-    att = torch.rand(1, 1, t, w, w)
     mid = t // 2
 
-    def timed(fn, budget_s, max_n):
-        fn()                                     # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 1 or (time.perf_counter() - t0 < budget_s and n < max_n):
-            fn()
-            n += 1
-        return (time.perf_counter() - t0) / n
-
-    def vit():
+    def clip():
         with torch.no_grad():
-            vref.inference_ref(sd, frames)
-
-    def stft_and_train():
-        with torch.no_grad():
+            att = vref.clip_normalise_ref(vref.inference_ref(sd, frames))[None]       # [1,1,T,W,W]
             y = sref.stft_ref(audio, args.fft_len, hop)
             x = y + 0.1 * torch.randn_like(y)
         opt.zero_grad()
@@ -104,12 +94,25 @@ def cpu_baseline(args):
         loss.backward()
         opt.step()
 
-    t_vit = timed(vit, 8.0, 6) * (t / vit_frames)          # ViT cost is linear in the number of (independent) frames
-    t_train = timed(stft_and_train, 8.0, 6)
-    return {"value": 1.0 / (t_vit + t_train), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"fp32 torch CPU oracle, batch 1: ViT-S/8 attention frames timed on {vit_frames} of the {t} "
-                      f"{w}x{w} frames and scaled ({t_vit:.2f} s/clip) + {args.fft_len}-pt STFT + AVSE fwd/bwd/Adam "
-                      f"({t_train:.2f} s/clip); os.cpu_count()={os.cpu_count()}"}
+    warm, times, t_start = 2, [], time.perf_counter()
+    for _ in range(warm):
+        clip()
+    while len(times) < 5 or (time.perf_counter() - t_start < 25.0 and len(times) < 9):
+        t0 = time.perf_counter()
+        clip()
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": 1.0 / med, "unit": "clips/s", "cores": cores, "cores_note": f"cgroup quota / affinity of this job; os.cpu_count()={os.cpu_count()}",
+            "kind": "port",
+            "sample": f"fp32 torch CPU oracle, batch 1, whole clips: ViT-S/8 attention frames of all {t} {w}x{w} frames + "
+                      f"{args.fft_len}-pt STFT + noise + AVSE fwd/bwd/Adam; {warm} warm-ups, median of {len(times)} timed clips "
+                      f"({med:.2f} s/clip, min {min(times):.2f}, max {max(times):.2f})"}
+
+
+def lib_sha256():
+    import hashlib
+    path = os.path.join(ROOT, "maavss_amd", "lib", "libmaavss_hip.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.isfile(path) else None
 
 
 def host_cores():
@@ -155,8 +158,8 @@ def main():
     b, t, w, hpf = args.batch, args.frames, args.framesize, args.hops_per_frame
     hop, length, t_a = maavss_amd.calc_hop_size(t, hpf, 30, 16000)
     n_bins = args.fft_len // 2 + 1
-    torch.manual_seed(1234 + rank)
-    frames, audio = synthetic_inputs(torch, b, t, w, length, 1234 + rank, dev)
+    torch.manual_seed(1234)                  # replicas: identical initialisation on every rank (TrainStep also broadcasts rank 0's)
+    frames, audio = synthetic_inputs(torch, b, t, w, length, 1234 + rank, dev)      # data: a different shard per rank
 
     va = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth", device=dev)   # random init: no network
     if args.vit_chunk:
@@ -170,7 +173,7 @@ def main():
                                                   spatial_match="adaptive")
         spatial = "adaptive"
     model = model.to(dev).train()
-    step_fn = maavss_amd.TrainStep(model, lr=1e-5, loss_coeff=0.001, num_seq=1)
+    step_fn = maavss_amd.TrainStep(model, lr=1e-5, loss_coeff=0.001, num_seq=1, sync_bn=args.sync_bn)
     mid = t // 2
     attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
 
@@ -203,6 +206,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = el.item()
     loss_val = float(losses[2].item())
+    # the same K steps once more without the per-entry-point HIP events (transparency: what the events cost)
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + args.steps + i)
+    sync_all()
+    elapsed_plain = time.perf_counter() - t1
 
     if rank == 0:
         summ = timer.summary()
@@ -271,6 +280,9 @@ def main():
             a0 = summ["maavss_stft_fwd"]["args"][0]
             per = a0[1] * (4.0 * a0[2] + 2 * 2.0 * a0[7] * a0[8] * 4.0)
             stage_row("maavss_stft_fwd", bytes_=per * summ["maavss_stft_fwd"]["calls"])
+            if "stft_fwd" in stages:
+                stages["stft_fwd"]["note"] = ("one launch per step over B*(T_a+1) frames: at B=32 that is ~4k waves = one wave round of "
+                                              "the chip, so the figure is launch/latency-bound, not a bandwidth limit (DESIGN.md 9)")
         if "maavss_adam_step" in summ:     # p, g, m, v read + p, m, v written: 28 B per parameter
             stage_row("maavss_adam_step", bytes_=sum(28.0 * a[4] for a in summ["maavss_adam_step"]["args"]))
         # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
@@ -279,13 +291,19 @@ def main():
         if roofline is not None and os.path.isfile(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
+            # the counters describe the kernels of the build they were taken with: a profile of another library is stale
+            if pmc.get("lib_sha256") != lib_sha256():
+                roofline["traffic_note"] = ("profiles/pmc_hbm_traffic_latest.json was taken with another build of libmaavss_hip.so "
+                                            f"(tag {pmc.get('tag')}); traffic left null")
+                pmc = {"kernels": []}
             stem = roofline["kernel"].replace("maavss_", "") + "_kernel"
             rows = [r for r in pmc["kernels"] if stem in r["kernel"]]
             n = sum(r["launches"] for r in rows)
             if n:
                 mb = sum(r["launches"] * (r["fetch_MB_per_launch_x2_corrected"] + r["write_MB_per_launch"]) for r in rows) / n
                 roofline["traffic"] = round(mb * 1e6)
-                roofline["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_hbm_traffic_latest.json)"
+                roofline["traffic_unit"] = (f"bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_hbm_traffic_latest.json, "
+                                            f"tag {pmc.get('tag')}, same libmaavss_hip.so)")
         breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:12]}
         if args.verbose:
             shapes = {}
@@ -308,10 +326,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precise else "bf16", "data": "synthetic",
+            "ms_per_step_without_kernel_events": round(elapsed_plain / args.steps * 1e3, 3),
             "config": {"workload": f"batch={b}/GPU, {t} frames {w}x{w}, {args.fft_len}-pt STFT, ViT-S/8 attention extraction "
                                    f"(bf16 MFMA) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
                        "parallelism": f"dp{world}", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
+                       "vit": "bf16", "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
+                       "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank",
                        "loss": loss_val},
             "roofline": roofline,
             "stages": stages,

@@ -115,6 +115,25 @@ int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argm
                            float* dbeta, int accumulate, float* ws, int B, int T, int H, int W, int C, int pool,
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
 
+/* Global-batch BatchNorm under data parallelism (the reference normalises over the WHOLE batch on one device,
+ * avse_model_final.py:35,40,45,50,55,103): split forms whose per-channel sums -- double sums[2*C + 1] = {sum, sum^2 (or
+ * sum g, sum g*z), element count} -- are all-reduced by the host (RCCL) between the two halves.  bwd_finish takes this
+ * rank's sums for dgamma / dbeta (the gradient all-reduce adds the ranks) and the reduced ones for the dx coefficients;
+ * coef: 3*C floats (as left by maavss_bn_pool_act_bwd in its ws). */
+int maavss_bn_partials_to_sums(const float* partials, int nblk, int C, double count, double* sums,
+                               float* ws /* nullable, as bn_finalize */, void* stream);
+int maavss_bn_finalize_sums(const double* sums, int C, float eps, float momentum, float* mean, float* invstd,
+                            float* running_mean, float* running_var, void* num_batches_tracked, void* stream);
+int maavss_bn_pool_act_bwd_sums(const float* dout, const float* out, const void* argmax, const float* y, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, float* ws, double* sums, int B,
+                                int T, int H, int W, int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p,
+                                int64_t os_c, void* stream);
+int maavss_bn_pool_act_bwd_finish(const float* dout, const float* out, const void* argmax, const float* y, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, float* dy, float* dgamma,
+                                  float* dbeta, int accumulate, const double* sums_local, const double* sums_global,
+                                  float* coef, int B, int T, int H, int W, int C, int pool, int act, int64_t os_b,
+                                  int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+
 /* ---- K10 Conv2d(k=(3,9), stride (sh,sw), pad (1,pw), bias=False) -- avse_model_final.py:98-102 ----
  * in_layout 0: x NCHW [B][Ci][H][W] (network input), 1: NHWC; y/dy NHWC [B][Ho][Wo][Co]; w [Co][Ci][3][9].
  * wgrad ws: maavss_conv2d_wgrad_nchunk(B,Ho,Wo,Ci,Co) * Co*Ci*27 floats. */

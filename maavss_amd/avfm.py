@@ -100,6 +100,9 @@ class _Fn(torch.autograd.Function):
         need = {n: ctx.needs_input_grad[2 + ctx.n_in + i] for i, n in enumerate(names)}
         grads = model._run_backward(ctx.mode, ctx.saved, d_outs, need)
         ctx.saved = None
+        flat = getattr(model, "_maavss_flat", None)
+        if flat is not None:      # FusedAdam steps only parameters that received a gradient (torch.optim.Adam semantics)
+            flat.mark(n for n in names if grads.get(n) is not None)
         return (None, None) + (None,) * ctx.n_in + tuple(grads.get(n) for n in names)
 
 

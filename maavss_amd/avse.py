@@ -80,6 +80,13 @@ def stft_decoder_plan(t_a, n_bins, t_v, s_v, latent, c_stft):
     return plan
 
 
+def _mark_touched(model, grads):
+    """tell a FusedAdam built on this model which parameters just received a gradient (torch.optim.Adam skips the rest)"""
+    flat = getattr(model, "_maavss_flat", None)
+    if flat is not None:
+        flat.mark(n for n, g in grads.items() if g is not None)
+
+
 class _AVSEFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward and backward are the HIP engine below."""
 
@@ -99,7 +106,48 @@ class _AVSEFunction(torch.autograd.Function):
         need = {n: ctx.needs_input_grad[3 + i] for i, n in enumerate(names)}
         grads = model._engine_backward(ctx.saved, d_a, d_v, d_fused, need)
         ctx.saved = None
+        _mark_touched(model, grads)
         return (None, None, None) + tuple(grads.get(n) for n in names)
+
+
+_FUSION_PARAMS = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.weight_ih_l0_reverse", "lstm.weight_hh_l0_reverse",
+                  "fc1.weight", "fc2.weight")
+
+
+class _FusionFunction(torch.autograd.Function):
+    """av_fusion_forward (avse_model_final.py:235-251) from given encodings, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, model, x_a, x_v, *params):
+        b, l, ts = x_a.shape[0], model.latent_channels, model.t_v * model.s_v
+        # torch.cat((x_v, x_a), dim=2) + flatten == two strided device copies into the LSTM sequence buffer
+        seq = torch.empty(b, l, 2 * ts, device=x_a.device, dtype=torch.float32)
+        seq[:, :, :ts].copy_(x_v.reshape(b, l, ts))
+        seq[:, :, ts:].copy_(x_a.reshape(b, l, ts))
+        sv = {}
+        fused = model._fusion_fwd(seq, sv)
+        ctx.model, ctx.saved, ctx.shape = model, sv, tuple(x_a.shape)
+        return fused
+
+    @staticmethod
+    def backward(ctx, d_fused):
+        model, sv = ctx.model, ctx.saved
+        grads = {}
+
+        def wgrad_gemm(name, dz, x):
+            if ctx.needs_input_grad[3 + _FUSION_PARAMS.index(name)]:
+                grads[name] = ops.gemm(dz, x, trans_a=True, trans_b=True, precise=ops.MODE_F32)
+
+        dgx = model._fusion_bwd(sv, d_fused.contiguous().float(), wgrad_gemm)
+        d_a = d_v = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            b, ts = ctx.shape[0], model.t_v * model.s_v
+            dseq = model._fusion_dseq(dgx, b)
+            d_v = dseq[:, :, :ts].reshape(ctx.shape) if ctx.needs_input_grad[2] else None
+            d_a = dseq[:, :, ts:].reshape(ctx.shape) if ctx.needs_input_grad[1] else None
+        ctx.saved = None
+        _mark_touched(model, grads)
+        return (None, d_a, d_v) + tuple(grads.get(n) for n in _FUSION_PARAMS)
 
 
 class _AEFunction(torch.autograd.Function):
@@ -119,6 +167,8 @@ class _AEFunction(torch.autograd.Function):
                                    "call model.train() for training steps")
         grads = model._ae_backward(ctx.saved, d_out.contiguous().float())
         ctx.saved = None
+        _mark_touched(model, {n: g for i, (n, g) in enumerate((n, grads.get(n)) for n in model._ae_param_names)
+                              if ctx.needs_input_grad[2 + i]})
         return (None, None) + tuple(grads.get(n) if ctx.needs_input_grad[2 + i] else None
                                     for i, n in enumerate(model._ae_param_names))
 
@@ -133,6 +183,7 @@ class AV_Fusion_Model_Frames(nn.Module):
         self.latent_channels = latent_channels
         self.output_stft_frames = hops_per_frame
         self.precise = bool(precise)
+        self._bn_sync = None
         if self.frame_channels != 1:
             raise ValueError("the visual encoder takes single-channel attention frames (avse_model_final.py:34)")
         if latent_channels not in (16,):
@@ -226,8 +277,17 @@ class AV_Fusion_Model_Frames(nn.Module):
         params = [pd[n] for n in self._param_names]
         return _AVSEFunction.apply(self, x_a, x_v, *params)
 
-    def av_fusion_forward(self, x_a_enc, x_v_enc):
-        raise NotImplementedError("call forward(); the fused engine does not expose the intermediate encodings")
+    def av_fusion_forward(self, x_a, x_v):
+        """avse_model_final.py:235-251: encodings x_a, x_v [B,16,T,S] -> x_av_fused [B,512] (cat on dim 2, flatten,
+        BiLSTM over the 16 channel steps, fc1, tanh, fc2, tanh) as one autograd node over the HIP engine;
+        differentiable in both encodings and the LSTM / fc weights."""
+        _lib.require_cuda(x_a, x_v)
+        want = (self.latent_channels, self.t_v, self.s_v)
+        if tuple(x_a.shape[1:]) != want or tuple(x_v.shape[1:]) != want or x_a.shape[0] != x_v.shape[0]:
+            raise ValueError(f"av_fusion_forward expects two [B, {want[0]}, {want[1]}, {want[2]}] encodings, got "
+                             f"{tuple(x_a.shape)} and {tuple(x_v.shape)}")
+        pd = dict(self.named_parameters())
+        return _FusionFunction.apply(self, x_a, x_v, *[pd[n] for n in _FUSION_PARAMS])
 
     # ---- engine ---------------------------------------------------------------------------------------
     def _vis(self, i):
@@ -343,6 +403,65 @@ class AV_Fusion_Model_Frames(nn.Module):
                 dcur = ops.conv2d_dgrad(dy, conv.weight.detach(), (hin, win), st, pw)
         return grads
 
+    def _fusion_fwd(self, seq, sv):
+        """av_fusion_forward (avse_model_final.py:235-251) on the LSTM sequence buffer seq [B,16,2*T*S]: BiLSTM over the
+        16 channel steps, fc1, tanh, fc2, tanh (K11-K13).  The Linear layers are weight-streaming (HBM-bound at
+        M = batch) with f32 weights in HBM, so they always use the exact-f32 MFMA: bf16 operand rounding would buy no
+        time there and costs accuracy; `precise` only switches the conv3d MFMAs."""
+        pr = ops.MODE_F32
+        b, l = seq.shape[0], self.latent_channels
+        seq2d = seq.view(b * l, seq.shape[2])
+        gx = torch.empty(b * l, 2048, device=seq.device, dtype=torch.float32)
+        ops.gemm(seq2d, self.lstm.weight_ih_l0.detach(), out=gx[:, :1024], precise=pr, split_k=1)
+        ops.gemm(seq2d, self.lstm.weight_ih_l0_reverse.detach(), out=gx[:, 1024:], precise=pr, split_k=1)
+        av, hp, gs, cs = ops.lstm_fwd(gx.view(b, l, 2, 4, 256), self.lstm.weight_hh_l0.detach(),
+                                      self.lstm.weight_hh_l0_reverse.detach())
+        h1 = ops.gemm(av.view(b, l * 512), self.fc1.weight.detach(), act=ops.ACT_TANH, precise=pr)
+        fused = ops.gemm(h1, self.fc2.weight.detach(), act=ops.ACT_TANH, precise=pr)
+        sv.update(seq=seq, av=av, hp=hp, gs=gs, cs=cs, h1=h1, fused=fused)
+        return fused
+
+    def _fusion_bwd(self, sv, dfused, wgrad_gemm):
+        """Backward of _fusion_fwd: parameter gradients through `wgrad_gemm(name, dz, x)`; returns the gate gradient dgx
+        [B*16, 2048], from which _fusion_dseq forms d(seq) -- kept apart so that the gradient all-reduce of the
+        fusion weights can start in between."""
+        pr = ops.MODE_F32
+        seq, fused, h1, av = sv["seq"], sv["fused"], sv["h1"], sv["av"]
+        b, l = seq.shape[0], self.latent_channels
+        dz2 = ops.act_bwd(dfused, fused, ops.ACT_TANH)
+        wgrad_gemm("fc2.weight", dz2, h1)
+        dh1 = ops.gemm(dz2, self.fc2.weight.detach(), trans_b=True, precise=pr)
+        dz1 = ops.act_bwd(dh1, h1, ops.ACT_TANH)
+        wgrad_gemm("fc1.weight", dz1, av.view(b, l * 512))
+        dav = ops.gemm(dz1, self.fc1.weight.detach(), trans_b=True, precise=pr)
+        dgx = ops.lstm_bwd(dav.view(b, l, 512), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach(),
+                           sv["gs"], sv["cs"]).view(b * l, 2048)
+        seq2d = seq.view(b * l, seq.shape[2])
+        hp2 = sv["hp"].view(b * l, 512)
+        wgrad_gemm("lstm.weight_ih_l0", dgx[:, :1024], seq2d)
+        wgrad_gemm("lstm.weight_ih_l0_reverse", dgx[:, 1024:], seq2d)
+        wgrad_gemm("lstm.weight_hh_l0", dgx[:, :1024], hp2[:, :256])
+        wgrad_gemm("lstm.weight_hh_l0_reverse", dgx[:, 1024:], hp2[:, 256:])
+        return dgx
+
+    def _fusion_dseq(self, dgx, b):
+        pr = ops.MODE_F32
+        dseq = ops.gemm(dgx[:, :1024], self.lstm.weight_ih_l0.detach(), trans_b=True, precise=pr)
+        ops.gemm(dgx[:, 1024:], self.lstm.weight_ih_l0_reverse.detach(), trans_b=True, out=dseq, beta=1, precise=pr)
+        return dseq.view(b, self.latent_channels, -1)
+
+    def set_bn_sync(self, reduce_fn):
+        """Global-batch BatchNorm for data-parallel training (EXTENSION; the reference is single-device, where BatchNorm
+        sees the whole batch, avse_model_final.py:35,...,103): `reduce_fn(t)` must sum the float64 tensor t in place over
+        the data-parallel ranks (trainer.TrainStep(sync_bn=True) installs one); None restores per-rank statistics."""
+        self._bn_sync = reduce_fn
+
+    def _bn_train_stats(self, part, count, bn):
+        if self._bn_sync is None:
+            return ops.bn_finalize(part, count, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
+        return ops.bn_finalize_synced(part, count, self._bn_sync, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      bn.eps, bn.momentum)
+
     def _engine_forward(self, x_a, x_v, train=True):
         # train=False (model.eval()): BatchNorm uses its running statistics and leaves them untouched (forward only)
         pr = ops.MODE_F32 if self.precise else ops.MODE_F16     # forward conv operands: IEEE half (or exact f32)
@@ -366,8 +485,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 y, part = ops.conv3d_igemm(act_in, wt, co, pad, pr, want_stats=train)
             hh, ww = y.shape[2], y.shape[3]
             if train:
-                mean, invstd = ops.bn_finalize(part, b * t * hh * ww, bn.running_mean, bn.running_var,
-                                               bn.num_batches_tracked, bn.eps, bn.momentum)
+                mean, invstd = self._bn_train_stats(part, b * t * hh * ww, bn)
             else:
                 mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             if i < 4:
@@ -389,9 +507,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             y = ops.conv2d_fwd(cur, conv.weight.detach(), st, pw, nchw)
             ho, wo = y.shape[1], y.shape[2]
             if train:
-                part = ops.bn_stats(y, co)
-                mean, invstd = ops.bn_finalize(part, b * ho * wo, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                               bn.eps, bn.momentum)
+                mean, invstd = self._bn_train_stats(ops.bn_stats(y, co), b * ho * wo, bn)
             else:
                 mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             y5 = y.view(b, 1, ho, wo, co)
@@ -409,23 +525,12 @@ class AV_Fusion_Model_Frames(nn.Module):
             ho, wo = sv["aud"][-1]["hw"]
             _lib.call("maavss_adaptive_pool_fwd", cur.data_ptr(), seq_aud.data_ptr(), b, ho, wo, self.latent_channels,
                       self._enc_pool[0], self._enc_pool[1], self.latent_channels * 2 * ts, 1, 2 * ts, _lib.stream_ptr())
-        # --- fusion: BiLSTM over the 16 channel steps, fc1, fc2 (K11-K13).  The Linear layers are weight-streaming
-        # (HBM-bound at M = batch) with f32 weights in HBM, so they always use the exact-f32 MFMA: bf16 operand
-        # rounding would buy no time there and costs accuracy; `precise` only switches the conv3d MFMAs.
+        fused = self._fusion_fwd(seq, sv)
         pr = ops.MODE_F32
-        l = self.latent_channels
-        seq2d = seq.view(b * l, 2 * ts)
-        gx = torch.empty(b * l, 2048, device=dev, dtype=torch.float32)
-        ops.gemm(seq2d, self.lstm.weight_ih_l0.detach(), out=gx[:, :1024], precise=pr, split_k=1)
-        ops.gemm(seq2d, self.lstm.weight_ih_l0_reverse.detach(), out=gx[:, 1024:], precise=pr, split_k=1)
-        av, hp, gs, cs = ops.lstm_fwd(gx.view(b, l, 2, 4, 256), self.lstm.weight_hh_l0.detach(),
-                                      self.lstm.weight_hh_l0_reverse.detach())
-        h1 = ops.gemm(av.view(b, l * 512), self.fc1.weight.detach(), act=ops.ACT_TANH, precise=pr)
-        fused = ops.gemm(h1, self.fc2.weight.detach(), act=ops.ACT_TANH, precise=pr)
         # --- heads (K14)
         a = ops.gemm(fused, self.a_fc1[0].weight.detach(), act=ops.ACT_TANH, precise=pr)
         v = ops.gemm(fused, self.v_fc1[0].weight.detach(), act=ops.ACT_SIGMOID, precise=pr)
-        sv.update(av=av, hp=hp, gs=gs, cs=cs, h1=h1, fused=fused, a=a, v=v)
+        sv.update(a=a, v=v)
         a_out = a.view(b, 2, self.output_stft_frames, self.n_bins)
         v_out = v.view(b, self.frame_channels, w, w)
         return (a_out, v_out, fused), sv
@@ -455,7 +560,7 @@ class AV_Fusion_Model_Frames(nn.Module):
 
         b, l, t = sv["x_v"].shape[0], self.latent_channels, self.t_v
         ts = t * self.s_v
-        a, v, fused, h1, av = sv["a"], sv["v"], sv["fused"], sv["h1"], sv["av"]
+        a, v, fused = sv["a"], sv["v"], sv["fused"]
         # heads
         dfused = None
         if d_a is not None:
@@ -473,32 +578,15 @@ class AV_Fusion_Model_Frames(nn.Module):
             dfused = d_fused.contiguous().clone() if dfused is None else dfused.add_(d_fused)  # tiny [B,512] glue
         if dfused is None:
             raise _lib.MaavssError("backward called without any output gradient")
-        # fc2, fc1
-        dz2 = ops.act_bwd(dfused, fused, ops.ACT_TANH)
-        wgrad_gemm("fc2.weight", dz2, h1)
-        dh1 = ops.gemm(dz2, self.fc2.weight.detach(), trans_b=True, precise=pr)
-        dz1 = ops.act_bwd(dh1, h1, ops.ACT_TANH)
-        avf = av.view(b, l * 512)
-        wgrad_gemm("fc1.weight", dz1, avf)
-        dav = ops.gemm(dz1, self.fc1.weight.detach(), trans_b=True, precise=pr)
-        # LSTM
-        dgx = ops.lstm_bwd(dav.view(b, l, 512), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach(),
-                           sv["gs"], sv["cs"]).view(b * l, 2048)
-        seq2d = sv["seq"].view(b * l, 2 * ts)
-        hp2 = sv["hp"].view(b * l, 512)
-        wgrad_gemm("lstm.weight_ih_l0", dgx[:, :1024], seq2d)
-        wgrad_gemm("lstm.weight_ih_l0_reverse", dgx[:, 1024:], seq2d)
-        wgrad_gemm("lstm.weight_hh_l0", dgx[:, :1024], hp2[:, :256])
-        wgrad_gemm("lstm.weight_hh_l0_reverse", dgx[:, 1024:], hp2[:, 256:])
+        # fc2, fc1, LSTM
+        dgx = self._fusion_bwd(sv, dfused, wgrad_gemm)
         if on_fusion_done is not None:
             on_fusion_done()
         enc_need = any(need.get(n, False) for n in self._param_names
                        if n.startswith("visual_encoder.") or n.startswith("stft_encoder."))
         if not enc_need:
             return out_grads
-        dseq = ops.gemm(dgx[:, :1024], self.lstm.weight_ih_l0.detach(), trans_b=True, precise=pr)
-        ops.gemm(dgx[:, 1024:], self.lstm.weight_ih_l0_reverse.detach(), trans_b=True, out=dseq, beta=1, precise=pr)
-        dseq = dseq.view(b, l, 2 * ts)
+        dseq = self._fusion_dseq(dgx, b)
 
         def bn_grads(prefix, idx):
             nw, nb = f"{prefix}.{idx}.weight", f"{prefix}.{idx}.bias"
@@ -530,7 +618,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 dout, out, strides = dcur.view(b, 1, ho, wo, co), s["out"], None
             gw, gb, acc = bn_grads("stft_encoder", 3 * i + 1)
             dy = ops.bn_pool_act_bwd(dout, out, None, s["y"], s["mean"], s["invstd"], bn.weight.detach(), 1, ops.BN_TANH,
-                                     strides=strides, dgamma=gw, dbeta=gb, accumulate=acc).view(b, ho, wo, co)
+                                     strides=strides, dgamma=gw, dbeta=gb, accumulate=acc, reduce_fn=self._bn_sync).view(b, ho, wo, co)
             wname = f"stft_encoder.{3 * i}.weight"
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
@@ -555,7 +643,8 @@ class AV_Fusion_Model_Frames(nn.Module):
                 # first layer: the network input needs no gradient, so dy has one consumer, the weight gradient -- which
                 # forms it in its loader from the pooled gradient (no 1.6 GB dy tensor, no dx pass)
                 coef = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
-                                           ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(), coef_only=True)
+                                           ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(), coef_only=True,
+                                           reduce_fn=self._bn_sync)
                 if need.get(wname, False):
                     buf, beta = gbuf(wname)
                     ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
@@ -563,7 +652,8 @@ class AV_Fusion_Model_Frames(nn.Module):
                     out_grads[wname] = buf
                 continue
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
-                                     ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach())
+                                     ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(),
+                                     reduce_fn=self._bn_sync)
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:

@@ -17,7 +17,7 @@ def save_model(path, model, overwrite=False):
 
 
 def save_checkpoint(model_dict, opt_dict, epoch, loss, name, dir):
-    print(f"saving {name}.pt checkpoint - {loss} avg loss (val)")
+    print(f"[maavss_amd] writing checkpoint {dir}/{name}.pt (epoch {epoch}, validation loss {loss})")
     torch.save({"epoch": epoch, "model_state_dict": model_dict, "optimizer_state_dict": opt_dict, "loss": loss},
                f"{dir}/{name}.pt")
 
@@ -34,18 +34,17 @@ def load_checkpoint(model, optimizer, dir, auto=True, path=None, load_opt=False)
     if auto:
         path = latest_file(dir, "pt")
         if path is None:
-            print("checkpoint not found, aborting cp load")
+            print(f"[maavss_amd] no *.pt checkpoint in {dir}: nothing loaded")
             return None
     elif path is None:
         return None
-    print(f"loading model checkpoint from {path}")
+    print(f"[maavss_amd] reading checkpoint {path}")
     map_location = next(model.parameters()).device
     checkpoint = torch.load(path, map_location=map_location, weights_only=True)
     model.load_state_dict(checkpoint["model_state_dict"], strict=False)
     if load_opt:
-        print("trying to load opt")
         try:
             optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
         except Exception as e:      # noqa: BLE001 -- reference behaviour (utilities.py:193-196)
-            print(f"Error loading optimizer: {e}")
+            print(f"[maavss_amd] optimizer state of {path} not restored: {e}")
     return checkpoint

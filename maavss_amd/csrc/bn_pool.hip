@@ -394,3 +394,128 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
   MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");
   return MAAVSS_OK;
 }
+
+// ---- split forms for cross-rank (global-batch) BatchNorm statistics: the per-channel sums leave the device-side
+// reduction as doubles [2][C] (+ the element count in slot 2C), the host all-reduces them over the data-parallel group
+// (RCCL), and the finish kernels take the reduced sums.  Single-device semantics of avse_model_final.py:35,40,...,103
+// (one BatchNorm over the whole batch) when the batch is sharded over GPUs.
+__global__ __launch_bounds__(1024) void bn_sums_kernel(const float* __restrict__ partials, int nblk, int C, double count,
+                                                       double* __restrict__ sums) {
+  double s1, s2;
+  bn_sum_partials(partials, nblk, C, s1, s2);
+  const int c = threadIdx.x;
+  if (c < C) {
+    sums[c] = s1;
+    sums[C + c] = s2;
+  }
+  if (c == 0) sums[2 * C] = count;
+}
+
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, float eps, float momentum, float* __restrict__ mean,
+                                        float* __restrict__ invstd, float* __restrict__ running_mean,
+                                        float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
+  const int c = threadIdx.x;
+  const double count = sums[2 * C];
+  if (c < C) {
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+}
+
+// dgamma / dbeta from THIS rank's sums (the gradient all-reduce adds the ranks), dx coefficients from the global ones
+__global__ void bn_bwd_finalize_sums_kernel(const double* __restrict__ local, const double* __restrict__ global, int C,
+                                            const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                            float* __restrict__ coef, const float* __restrict__ beta_inv) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const bool inv = beta_inv != nullptr && fabsf(gamma[c]) >= BN_INV_MIN_GAMMA;
+  double l1 = local[c], l2 = local[C + c], g1 = global[c], g2 = global[C + c];
+  if (inv) {
+    l2 = (l2 - (double)beta_inv[c] * l1) / (double)gamma[c];
+    g2 = (g2 - (double)beta_inv[c] * g1) / (double)gamma[c];
+  }
+  if (dgamma != nullptr) {
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)l2;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)l1;
+  }
+  const double count = global[2 * C];
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = (float)(g1 / count);
+  coef[2 * C + c] = (float)(g2 / count);
+}
+
+extern "C" int maavss_bn_partials_to_sums(const float* partials, int nblk, int C, double count, double* sums, float* ws,
+                                          void* stream) {
+  MAAVSS_CHECK_ARG(partials && sums && nblk > 0 && C > 0 && C <= 64 && count > 0, "bn_partials_to_sums: bad arguments");
+  if (nblk > 512 && ws != nullptr) {
+    const int rpb = cdiv(nblk, 256), nb1 = cdiv(nblk, rpb);
+    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(nb1), dim3(256), 0, (hipStream_t)stream, partials, ws, nblk, 2 * C, rpb);
+    MAAVSS_LAUNCH_CHECK("bn_reduce_rows_kernel");
+    partials = ws;
+    nblk = nb1;
+  }
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, nblk, C, count, sums);
+  MAAVSS_LAUNCH_CHECK("bn_sums_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_bn_finalize_sums(const double* sums, int C, float eps, float momentum, float* mean, float* invstd,
+                                       float* running_mean, float* running_var, void* num_batches_tracked, void* stream) {
+  MAAVSS_CHECK_ARG(sums && mean && invstd && C > 0 && C <= 64, "bn_finalize_sums: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, C, eps, momentum, mean, invstd,
+                     running_mean, running_var, (long long*)num_batches_tracked);
+  MAAVSS_LAUNCH_CHECK("bn_finalize_sums_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_bn_pool_act_bwd_sums(const float* dout, const float* out, const void* argmax, const float* y,
+                                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                           float* ws, double* sums, int B, int T, int H, int W, int C, int pool, int act,
+                                           int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream) {
+  MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && ws && sums, "bn_pool_act_bwd_sums: null pointer");
+  if (int rc = check_geom("bn_pool_act_bwd_sums", B, T, H, W, C, pool)) return rc;
+  MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_bwd_sums: argmax buffer required when pool > 1");
+  hipStream_t st = (hipStream_t)stream;
+  PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
+  const int64_t rows = (int64_t)g.BT * g.Hp * g.Wp;
+  const int nblk = maavss_bn_stats_nblk(rows);
+  const bool inverse = beta != nullptr && act == ACT_LEAKY;
+  hipLaunchKernelGGL(bn_pool_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dout, out, (const unsigned char*)argmax,
+                     y, mean, invstd, inverse ? gamma : nullptr, ws, g, act, (int64_t)cdiv(rows, nblk));
+  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_reduce_kernel");
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(1), dim3(1024), 0, st, ws, nblk, C, (double)g.BT * H * W, sums);
+  MAAVSS_LAUNCH_CHECK("bn_sums_kernel");
+  return MAAVSS_OK;
+}
+
+extern "C" int maavss_bn_pool_act_bwd_finish(const float* dout, const float* out, const void* argmax, const float* y,
+                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                             float* dy, float* dgamma, float* dbeta, int accumulate, const double* sums_local,
+                                             const double* sums_global, float* coef, int B, int T, int H, int W, int C, int pool,
+                                             int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream) {
+  MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && sums_local && sums_global && coef,
+                   "bn_pool_act_bwd_finish: null pointer");
+  if (int rc = check_geom("bn_pool_act_bwd_finish", B, T, H, W, C, pool)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
+  const bool inverse = beta != nullptr && act == ACT_LEAKY;
+  hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3(1), dim3(64), 0, st, sums_local, sums_global, C, gamma, invstd, dgamma,
+                     dbeta, accumulate, coef, inverse ? beta : nullptr);
+  MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_sums_kernel");
+  if (dy == nullptr) return MAAVSS_OK;
+  const int64_t total = (int64_t)g.BT * H * W * (C / 4);
+  hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
+                     (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);
+  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");
+  return MAAVSS_OK;
+}

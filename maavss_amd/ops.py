@@ -160,6 +160,22 @@ def bn_finalize(part, count, running_mean=None, running_var=None, num_batches_tr
     return mean, invstd
 
 
+def bn_finalize_synced(part, count, reduce_fn, running_mean=None, running_var=None, num_batches_tracked=None, eps=BN_EPS,
+                        momentum=BN_MOMENTUM):
+    """bn_finalize with the per-channel sums (and the element count) all-reduced over the data-parallel ranks by
+    `reduce_fn(double tensor [2C+1])` in between: global-batch statistics, as on the reference's single device."""
+    nblk, _, c = part.shape
+    sums = torch.empty(2 * c + 1, device=part.device, dtype=torch.float64)
+    ws = torch.empty(256 * 2 * c, device=part.device, dtype=torch.float32) if nblk > 512 else None
+    call("maavss_bn_partials_to_sums", ptr(part), nblk, c, float(count), ptr(sums), ptr(ws), stream_ptr())
+    reduce_fn(sums)
+    mean = torch.empty(c, device=part.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    call("maavss_bn_finalize_sums", ptr(sums), c, float(eps), float(momentum), ptr(mean), ptr(invstd), ptr(running_mean),
+         ptr(running_var), ptr(num_batches_tracked), stream_ptr())
+    return mean, invstd
+
+
 def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     """eval-mode BatchNorm statistics (running mean / var) in the (mean, invstd) form the fused kernels take."""
     _f32(running_mean, running_var)
@@ -189,7 +205,9 @@ def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=N
 
 
 def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,
-                    accumulate=False, dy=None, coef_only=False, beta=None):
+                    accumulate=False, dy=None, coef_only=False, beta=None, reduce_fn=None):
+    """`reduce_fn` (global-batch BatchNorm under data parallelism): all-reduces the [2C+1] double sums between the
+    reduction and the dx pass; dgamma / dbeta keep this rank's sums (the gradient all-reduce adds the ranks)."""
     _f32(y, mean, invstd, gamma)
     b, t, h, w, c = y.shape
     hp, wp = h // pool, w // pool
@@ -200,6 +218,17 @@ def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=N
     if dy is None and not coef_only:
         dy = torch.empty_like(y)
     _f32(beta)
+    if reduce_fn is not None:
+        geom = (b, t, h, w, c, pool, act, *[int(s) for s in strides], stream_ptr())
+        local = torch.empty(2 * c + 1, device=y.device, dtype=torch.float64)
+        call("maavss_bn_pool_act_bwd_sums", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+             ptr(ws), ptr(local), *geom)
+        glob = local.clone()
+        reduce_fn(glob)
+        coef = ws[2 * c * nblk:]
+        call("maavss_bn_pool_act_bwd_finish", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+             ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(local), ptr(glob), ptr(coef), *geom)
+        return coef.view(3, c) if coef_only else dy
     call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(dy),
          ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), b, t, h, w, c, pool, act, *[int(s) for s in strides],
          stream_ptr())

@@ -14,8 +14,10 @@ with every tensor operation in libmaavss_hip.so.  Two entry levels:
                    the encoder backward, fused Adam.  This is what bench.py times.
 
 Data parallelism: clips are independent, the batch dimension is sharded across ranks, weights
-are replicated; the only collective is the gradient sum.  BatchNorm uses per-rank batch statistics (as
-torch DDP does without SyncBatchNorm) -- documented in DESIGN.md.
+are replicated (rank 0's parameters and BatchNorm buffers are broadcast when a TrainStep is built, as DDP
+does); the only mandatory collective is the gradient sum.  BatchNorm uses per-rank batch statistics by default
+(as torch DDP does without SyncBatchNorm); `TrainStep(sync_bn=True)` all-reduces the per-channel sums instead,
+which reproduces the single-device reference on the concatenated batch -- documented in DESIGN.md.
 """
 import torch
 
@@ -53,7 +55,7 @@ class FlatParams:
         dev = named[0][1].device
         self.params = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.grads = torch.zeros(self.total, device=dev, dtype=torch.float32)
-        self.param_views, self.grad_views = {}, {}
+        self.param_views, self.grad_views, self.tensors = {}, {}, {}
         for n, p in fusion + other:
             o, k = self.offsets[n], p.numel()
             pv = self.params[o:o + k].view(p.shape)
@@ -61,38 +63,100 @@ class FlatParams:
             p.data = pv
             gv = self.grads[o:o + k].view(p.shape)
             p.grad = gv
-            self.param_views[n], self.grad_views[n] = pv, gv
+            self.param_views[n], self.grad_views[n], self.tensors[n] = pv, gv, p
+        # names whose gradient was produced since the last zero_grad(): Adam skips the others, like torch.optim.Adam skips
+        # parameters whose .grad is None (e.g. stft_decoder.* under forward(), frozen sub-networks)
+        self.touched = set()
+        model._maavss_flat = self
+
+    def mark(self, names):
+        self.touched.update(names)
+
+    def check_links(self):
+        """The model's parameters must still be the flat views (model.to() / .float() / zero_grad(set_to_none=True) after
+        construction re-home them).  A detached .grad is folded back in (None = no gradient this step, a foreign tensor
+        is copied); a re-homed parameter cannot be repaired silently and raises."""
+        from ._lib import MaavssError
+        for n, p in self.tensors.items():
+            if p.data_ptr() != self.param_views[n].data_ptr():
+                raise MaavssError(f"parameter {n} no longer lives in the flat buffer (model.to()/.float() after the optimizer "
+                                  f"was built?): build FusedAdam / TrainStep after moving the model")
+            gv = self.grad_views[n]
+            if p.grad is None:
+                self.touched.discard(n)
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+                p.grad = gv
+                self.touched.add(n)
 
 
 class FusedAdam:
-    """torch.optim.Adam semantics (betas .9/.999, eps 1e-8, no weight decay, no amsgrad) in one HIP kernel."""
+    """torch.optim.Adam semantics (betas .9/.999, eps 1e-8, no weight decay, no amsgrad) in HIP launches over the flat
+    buffers.  Like torch, a parameter is only stepped when a backward pass produced a gradient for it since the last
+    zero_grad() (frozen sub-networks and stft_decoder.* under forward() are left alone, keep their moments and their
+    own step count); contiguous runs of stepped parameters share one launch -- one launch in the usual case."""
 
     def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else FlatParams(model_or_flat)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.exp_avg = torch.zeros_like(self.flat.params)
         self.exp_avg_sq = torch.zeros_like(self.flat.params)
-        self.step_count = 0
+        self.steps = {n: 0 for n in self.flat.names}          # per-parameter step count (torch keeps one per parameter)
+
+    @property
+    def step_count(self):
+        return max(self.steps.values())
+
+    @step_count.setter
+    def step_count(self, n):
+        self.steps = {k: int(n) for k in self.steps}
+
+    def _runs(self):
+        """[(lo, hi, step)] maximal runs of touched parameters with equal step counts, in buffer order."""
+        f, runs = self.flat, []
+        for n in f.names:
+            if n not in f.touched or not f.tensors[n].requires_grad:
+                continue
+            lo, st = f.offsets[n], self.steps[n] + 1
+            k = 1
+            for d in f.shapes[n]:
+                k *= d
+            hi = _align(lo + k)
+            if runs and runs[-1][1] == lo and runs[-1][2] == st:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi, st])
+            self.steps[n] = st
+        return runs
 
     def step(self, grad_scale=1.0):
-        self.step_count += 1
-        ops.adam_step(self.flat.params, self.flat.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
-                      self.betas, self.eps, grad_scale)
+        self.flat.check_links()
+        for lo, hi, st in self._runs():
+            hi = min(hi, self.flat.total)
+            ops.adam_step(self.flat.params[lo:hi], self.flat.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                          self.lr, st, self.betas, self.eps, grad_scale)
 
     def zero_grad(self, set_to_none=False):
-        self.flat.grads.zero_()        # memset; the flat views stay attached to p.grad
+        """memset of the flat gradient buffer; the views stay attached to p.grad whatever `set_to_none` says (gradients
+        are accumulated in place).  Parameters count as gradient-less until the next backward produces one."""
+        self.flat.check_links()
+        self.flat.grads.zero_()
+        self.flat.touched.clear()
 
     def state_dict(self):
         """torch.optim.Adam's layout (what utilities.save_checkpoint stores as 'optimizer_state_dict',
         utilities.py:168-175): per-parameter step / exp_avg / exp_avg_sq keyed by the position of the parameter in
-        model.parameters(), plus one param_group."""
+        model.parameters(), plus one param_group.  Parameters that were never stepped have no entry, as in torch."""
         f = self.flat
         state = {}
         for i, n in enumerate(f.torch_order):
+            if self.steps[n] == 0:
+                continue
             o, k = f.offsets[n], 1
             for d in f.shapes[n]:
                 k *= d
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": torch.tensor(float(self.steps[n])),
                         "exp_avg": self.exp_avg[o:o + k].view(f.shapes[n]).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + k].view(f.shapes[n]).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
@@ -102,7 +166,7 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         """Accepts the dict above and a reference checkpoint's torch.optim.Adam state (parameters the reference never
-        stepped -- stft_decoder.* under forward() -- have no entry there: their moments stay zero)."""
+        stepped -- stft_decoder.* under forward() -- have no entry there: their moments and step count stay zero)."""
         f = self.flat
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(f.torch_order):
@@ -113,7 +177,7 @@ class FusedAdam:
         self.eps = float(groups[0]["eps"])
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
-        steps = set()
+        self.steps = {n: 0 for n in f.names}
         for i, n in enumerate(f.torch_order):
             st = sd["state"].get(i, sd["state"].get(str(i)))
             if st is None:
@@ -123,10 +187,7 @@ class FusedAdam:
                 raise ValueError(f"optimizer state of parameter {i} ({n}) has shape {tuple(st['exp_avg'].shape)}, expected {f.shapes[n]}")
             self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): one fused step counter cannot represent that")
-        self.step_count = steps.pop() if steps else 0
+            self.steps[n] = int(float(st["step"]))
 
 
 class GradSync:
@@ -144,6 +205,19 @@ class GradSync:
         self.group = process_group
         self.grads, self.fusion_end = grads, fusion_end
         self._pending = None
+
+    def broadcast(self, tensors, src=0):
+        """Make the replicas identical: rank `src`'s values everywhere (parameters, BatchNorm buffers), as DDP does at
+        construction.  No-op with one rank."""
+        if self.enabled:
+            for t in tensors:
+                self.dist.broadcast(t, src=src, group=self.group)
+
+    def sum_(self, t):
+        """in-place sum of a small tensor over the ranks (global-batch BatchNorm sums)"""
+        if self.enabled:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def start_fusion(self):
         if self.enabled:
@@ -173,24 +247,33 @@ class TrainStep:
     """One optimizer step of the fusion network, autograd-free (see module docstring)."""
 
     def __init__(self, model, lr=1e-5, loss_coeff=0.001, num_seq=1, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None):
+                 process_group=None, sync_bn=False):
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.loss_coeff, self.num_seq = loss_coeff, num_seq
         self.sync = GradSync(self.flat.grads, self.flat.fusion_end, process_group)
-        self.need = {n: bool(p.requires_grad) for n, p in model.named_parameters()}
+        # replicas start identical: rank 0's weights (one flat buffer) and BatchNorm buffers, like DDP's constructor
+        self.sync.broadcast([self.flat.params] + [b for _, b in model.named_buffers()])
+        if sync_bn and self.sync.enabled:
+            model.set_bn_sync(self.sync.sum_)
         self.losses = None
 
     def __call__(self, x_a, x_v, y_a, y_v, optimizer_step=True, accumulate=False, last=True):
         """One window: forward, loss / num_seq, backward.  `accumulate` adds into the flat gradient buffer instead of
-        overwriting it; the gradient all-reduce and Adam run only when `last` (sliding_window_step drives both)."""
+        overwriting it; the gradient all-reduce and Adam run only when `last` (sliding_window_step drives both).
+        requires_grad is read at every call (toggle_* between steps take effect, as with autograd)."""
         m = self.model
+        need = {n: bool(p.requires_grad) for n, p in m.named_parameters()}
+        if not accumulate:
+            # gradients this step does not produce must not carry over (the engine overwrites the ones it does produce)
+            self.flat.touched.clear()
         (a, v, fused), sv = m._engine_forward(x_a, x_v, train=True)
         self.outputs = (a, v, fused)
         self.losses, d_a, d_v = ops.mse_pair(a, y_a.contiguous(), v, y_v.contiguous(), self.loss_coeff, self.num_seq)
-        m._engine_backward(sv, d_a, d_v, None, self.need, grads=self.flat.grad_views, accumulate=accumulate,
-                           on_fusion_done=self.sync.start_fusion if last else None)
+        out = m._engine_backward(sv, d_a, d_v, None, need, grads=self.flat.grad_views, accumulate=accumulate,
+                                 on_fusion_done=self.sync.start_fusion if last else None)
+        self.flat.mark(out.keys())
         if last:
             self.sync.finish()
             if optimizer_step:

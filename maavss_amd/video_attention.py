@@ -237,7 +237,8 @@ class VideoAttention:
 
     def _inference(self, frames):
         """Reference contract (video_attention.py:38-103): [T,3,H,W] float -> [T,1,H,W] float32 on the CPU."""
+        # `resize` is stored and never read by the reference's _inference (video_attention.py:29-30,38-103): same here.
+        # Frame sizes that are not multiples of 8: the reference crops to the patch grid and then fails on the shape
+        # mismatch of its assignment at :96; here the area outside the patch grid stays zero (documented extension).
         dev_frames = frames.to(self.device, dtype=torch.float32)
-        if self.resize is not None:
-            raise NotImplementedError("resize is unused by the reference's _inference and is not built")
         return self.attention_frames(dev_frames, clip_frames=0).cpu()

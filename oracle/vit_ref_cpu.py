@@ -79,45 +79,73 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
     return torch.cat([pos_embed[:, :1], patch], 1)
 
 
-def prepare_tokens(sd, frames):
+def _bf(x):
+    """round to bf16 (nearest even) and return as f32 -- the storage rounding of the HIP path"""
+    return x.to(torch.bfloat16).float()
+
+
+def prepare_tokens(sd, frames, emulate_bf16=False):
     b, _, h, w = frames.shape
-    x = F.conv2d(frames, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=PATCH)
+    if emulate_bf16:      # vit_patchify stores bf16 patches, the weight is bf16; bias + cls + pos stay f32 (row table)
+        x = F.conv2d(_bf(frames), _bf(sd["patch_embed.proj.weight"]), None, stride=PATCH) + sd["patch_embed.proj.bias"][None, :, None, None]
+    else:
+        x = F.conv2d(frames, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=PATCH)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat([sd["cls_token"].expand(b, -1, -1), x], 1)
     return x + interpolate_pos_embed(sd["pos_embed"], h // PATCH, w // PATCH)
 
 
-def block_forward(sd, i, x, return_attention=False):
+QSCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): the kernels run softmax on exp2
+
+
+def block_forward(sd, i, x, return_attention=False, emulate_bf16=False):
+    """One pre-LN block.  `emulate_bf16` rounds exactly where the HIP kernels store 16-bit values: the
+    weights, the LayerNorm output, q (after the log2(e)/8 scale) / k / v, the exponentiated probabilities that enter
+    P.V (the row sum keeps the unrounded f32 values), the attention output and the GELU output; accumulation, biases,
+    residual stream and softmax stay f32.  What is left between this and the kernels is summation order, the deferred
+    running-maximum of the online softmax and the polynomial GELU (|err| < 1e-4)."""
     p = f"blocks.{i}."
     b, n, _ = x.shape
-    y = F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS)
-    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    r = _bf if emulate_bf16 else (lambda t: t)
+    y = r(F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS))
+    qkv = F.linear(y, r(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"])
+    if emulate_bf16:
+        qkv = torch.cat([qkv[..., :DIM] * QSCALE, qkv[..., DIM:]], -1)
+        qkv = _bf(qkv)
     qkv = qkv.reshape(b, n, 3, HEADS, DIM // HEADS).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    att = (q @ k.transpose(-2, -1)) * ((DIM // HEADS) ** -0.5)
-    att = att.softmax(-1)
-    if return_attention:
-        return att
-    y = (att @ v).transpose(1, 2).reshape(b, n, DIM)
-    x = x + F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
-    y = F.layer_norm(x, (DIM,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS)
-    y = F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-    return x + F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    if emulate_bf16:
+        s = q @ k.transpose(-2, -1)                         # log2 units
+        pexp = torch.exp2(s - s.max(-1, keepdim=True).values)
+        if return_attention:
+            return pexp / pexp.sum(-1, keepdim=True)
+        y = (_bf(pexp) @ v) / pexp.sum(-1, keepdim=True)
+        y = _bf(y.transpose(1, 2).reshape(b, n, DIM))
+    else:
+        att = (q @ k.transpose(-2, -1)) * ((DIM // HEADS) ** -0.5)
+        att = att.softmax(-1)
+        if return_attention:
+            return att
+        y = (att @ v).transpose(1, 2).reshape(b, n, DIM)
+    x = x + F.linear(y, r(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
+    y = r(F.layer_norm(x, (DIM,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS))
+    y = r(F.gelu(F.linear(y, r(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])))
+    return x + F.linear(y, r(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
 
 
-def get_last_selfattention(sd, frames, return_hidden=False):
-    x = prepare_tokens(sd, frames)
+def get_last_selfattention(sd, frames, return_hidden=False, emulate_bf16=False):
+    x = prepare_tokens(sd, frames, emulate_bf16)
     hidden = [x]
     for i in range(DEPTH - 1):
-        x = block_forward(sd, i, x)
+        x = block_forward(sd, i, x, emulate_bf16=emulate_bf16)
         hidden.append(x)
-    att = block_forward(sd, DEPTH - 1, x, return_attention=True)
+    att = block_forward(sd, DEPTH - 1, x, return_attention=True, emulate_bf16=emulate_bf16)
     return (att, hidden) if return_hidden else att
 
 
-def cls_attention(sd, frames):
+def cls_attention(sd, frames, emulate_bf16=False):
     """[B,3,H,W] -> CLS-row attention without the CLS column, [B, 6, N]."""
-    return get_last_selfattention(sd, frames)[:, :, 0, 1:]
+    return get_last_selfattention(sd, frames, emulate_bf16=emulate_bf16)[:, :, 0, 1:]
 
 
 def attention_frames_from_cls(cls_att, h_tok, w_tok):
@@ -130,12 +158,12 @@ def attention_frames_from_cls(cls_att, h_tok, w_tok):
     return a[:, None]
 
 
-def inference_ref(sd, frames):
+def inference_ref(sd, frames, emulate_bf16=False):
     """VideoAttention._inference: frames [T,3,H,W] -> [T,1,H,W] (H, W cropped to multiples of 8 are
     written into a zero canvas of the original size, video_attention.py:39,43-47,96)."""
     t, _, h, w = frames.shape
     hc, wc = h - h % PATCH, w - w % PATCH
-    att = cls_attention(sd, frames[:, :, :hc, :wc])
+    att = cls_attention(sd, frames[:, :, :hc, :wc], emulate_bf16)
     out = torch.zeros(t, 1, h, w)
     out[:, :, :hc, :wc] = attention_frames_from_cls(att, hc // PATCH, wc // PATCH)
     return out

@@ -67,3 +67,43 @@ def test_gradsync_noop_single_process():
     s.start_fusion()
     s.finish()
     assert torch.equal(g, torch.ones(10))
+
+
+def _replica_worker(rank, world, port, out_dir):
+    """TrainStep's constructor must leave every rank with rank 0's parameters and BatchNorm buffers (the
+    replicas used to start from different seeds and were never synchronised)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import maavss_amd
+    torch.manual_seed(100 + rank)                      # deliberately different initialisations
+    model = maavss_amd.AV_Fusion_Model_Frames([2, 2, 64, 129], [2, 1, 8, 128, 128], 8)
+    with torch.no_grad():
+        for _, b in model.named_buffers():
+            if b.dtype.is_floating_point:
+                b.add_(float(rank))
+    before = model.fc2.weight.detach().clone()
+    step = maavss_amd.TrainStep(model, lr=1e-3, sync_bn=True)      # CPU tensors: construction only, no kernel runs
+    assert step.sync.enabled and model._bn_sync is not None
+    if rank > 0:
+        assert not torch.equal(before, model.fc2.weight.detach()), "rank>0 kept its own initialisation"
+    # the model's parameters are still views of the flat buffer after the broadcast
+    for n, p in model.named_parameters():
+        if n in step.flat.param_views:
+            assert p.data_ptr() == step.flat.param_views[n].data_ptr(), n
+    t = torch.zeros(3, dtype=torch.float64) + rank + 1
+    model._bn_sync(t)                                   # the reduce function SyncBN hands to the engine
+    assert torch.equal(t, torch.full((3,), float(sum(range(1, world + 1))), dtype=torch.float64))
+    torch.save({"params": step.flat.params.clone(), "buffers": {k: v.clone() for k, v in model.named_buffers()}},
+               os.path.join(out_dir, f"replica_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainstep_broadcasts_parameters_and_buffers_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    reps = [torch.load(os.path.join(tmp_path, f"replica_{r}.pt"), weights_only=True) for r in range(world)]
+    assert torch.equal(reps[0]["params"], reps[1]["params"])
+    assert reps[0]["params"].abs().sum() > 0
+    for k, v in reps[0]["buffers"].items():
+        assert torch.equal(v, reps[1]["buffers"][k]), k
