@@ -220,7 +220,11 @@ int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* ---- K1-K6 DINO ViT-S/8 attention-frame extractor ------------------------------------------------
  * What VideoAttention._inference (video_attention.py:38-103) obtains from dino's
  * VisionTransformer.get_last_selfattention (external module, call site video_attention.py:52), batched
- * over frames.  bf16 = raw uint16 bits.  rows = frames * ntok, ntok = (H/8)*(W/8) + 1.
+ * over frames.  rows = frames * ntok, ntok = (H/8)*(W/8) + 1.
+ * dtype    : the 16-bit storage / MFMA operand format of the activations and weights, raw uint16 bits: 0 = bf16,
+ *            2 = IEEE half (same MFMA rate, 3 more mantissa bits; the LayerNorm-ed / softmax-bounded activations of the
+ *            extractor fit its range).  "bf16" below stands for whichever is selected; accumulation, residual stream,
+ *            LayerNorm and softmax are always f32.
  * patchify : frames [F][3][H][W] f32 -> a [rows][192] bf16 (CLS rows zero).
  * gemm     : C = epilogue(A[M][K] bf16 . W[N][K]^T bf16); N % 128 == 0, K % 64 == 0.  epilogue 0: +bias,
  *            columns < qscale_cols times qscale -> bf16;  1: +bias, exact GELU -> bf16;  2: C(f32) += acc + bias
@@ -231,11 +235,11 @@ int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
  * attn_maps: video_attention.py:80-96 + av_dataset.py:328: head sum, x(1/frame max), nearest x8 upsample,
  *            x(1/clip max over groups of clip_frames frames; 0 = skip) -> out [F][1][H][W] f32 (zero outside the
  *            patch grid); ws = F * ((H/8)*(W/8) + 1) floats. */
-int maavss_vit_patchify(const float* frames, void* a, int64_t n_frames, int H, int W, void* stream);
+int maavss_vit_patchify(const float* frames, void* a, int64_t n_frames, int H, int W, int dtype, void* stream);
 int maavss_vit_gemm(const void* A, int lda, const void* W, const float* bias, const float* table, int period, void* C,
-                    int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale, void* stream);
+                    int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale, int dtype, void* stream);
 int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int dim,
-                         float eps, void* stream);
+                         float eps, int dtype, void* stream);
 /* panel GEMM for the K = 384 layers with the preceding LayerNorm fused (dino Block: norm1->attn.qkv, attn.proj,
  * norm2->mlp.fc1): C = epilogue(LN(X)[M][384] . W[N][384]^T) when X (f32) is given, or A (bf16, [M][lda]) . W^T
  * otherwise; exactly one of X / A is non-null.  epilogue 0 / 1 / 2 as in maavss_vit_gemm (bf16+q-scale, bf16+GELU,
@@ -244,9 +248,10 @@ int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, 
  * don't-care values) so that its counted DMA waits stay exact. */
 int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
                           float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M,
-                          int N, int epilogue, int qscale_cols, float qscale, void* stream);
-int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, void* stream);
-int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, void* stream);
+                          int N, int epilogue, int qscale_cols, float qscale, int dtype, void* stream);
+int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
+                    void* stream);
+int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
                          int clip_frames, int attn_diff /* av_dataset.py:323-326, needs clip_frames > 0 */, void* stream);
 

@@ -49,6 +49,33 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+// 16-bit storage formats of the ViT path (include/maavss.h `dtype`): 0 = bf16, 2 = IEEE half (same MFMA rate, 3 more
+// mantissa bits, range +-65504 -- the LayerNorm-ed / bounded activations of the extractor fit).  Numbering = MODE_* of mma.h.
+template <int MODE>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  if constexpr (MODE == 2) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));   // round-to-nearest-even per element
+  } else {
+    return pack_bf2(lo, hi);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ unsigned short cvt16(float f) {
+  if constexpr (MODE == 2) {
+    const _Float16 hv = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, hv);
+  } else {
+    return f2bf(f);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ float up16(unsigned short b) {
+  if constexpr (MODE == 2) return (float)__builtin_bit_cast(_Float16, b);
+  else return bf2f(b);
+}
+
 // Two 4 x 16-bit halves (e.g. two ds_read_b64_tr_b16 results) -> one 8 x 16-bit MFMA fragment, as a pure
 // register-pair concatenation (an element-wise vector initialiser makes hipcc emit per-element pack code).
 __device__ __forceinline__ bf16x8 concat4(bf16x4 lo, bf16x4 hi) {

@@ -71,3 +71,21 @@ struct Mma<MODE_F32> {
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
   }
 };
+
+// 32x32x16 forms (f32x16 accumulator: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); A/B: lane (r = lane & 31,
+// h = lane >> 5) holds A[row r][k = 8h + j] / B[k = 8h + j][col r], j = 0..7).  Half the vector-issue hold per FLOP of the
+// 16x16x32 forms (8 of 32 cycles instead of 8 of 16).
+template <int MODE>
+struct Mma32;
+template <>
+struct Mma32<MODE_BF16> {
+  static __device__ __forceinline__ void mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma32<MODE_F16> {
+  static __device__ __forceinline__ void mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), acc, 0, 0, 0);
+  }
+};

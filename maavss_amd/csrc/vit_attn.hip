@@ -2,24 +2,12 @@
 // attention of the last block -- what dino's Attention.forward / get_last_selfattention compute for the
 // reference's video_attention.py:52-56.
 //
-// vit_attn_kernel: flash-style, never materialises the N x N scores.  Workgroup = 128 query rows of one
-// (frame, head); each of the 4 waves owns 32 rows (two 16-row tiles).  Per 64-key tile:
-//   S^T = K Q^T  on v_mfma_f32_16x16x32_bf16 with K as the A operand: the accumulator then has the QUERY on the
-//         lane and 16 keys in registers, so the softmax row maximum is a register reduction plus two cross-lane
-//         exchanges (lanes l, l^16, l^32, l^48), and
-//   O^T += V^T P^T takes the exponentiated accumulator, packed to bf16, DIRECTLY as its B operand (the MFMA k
-//         slot (g, e) is assigned to key 32*ks + 16*(e>>2) + 4*g + (e&3), and V^T fragments are read with the same
-//         assignment by ds_read_b64_tr_b16) -- P never goes through LDS.
-// K/V tiles are double-buffered in LDS (K XOR-swizzled per 16-B chunk for ds_read_b128, V per 32-B granule for
-// the transposed reads: both conflict-free for the hardware's lane groups); the next tile's global loads (wave-uniform
-// frame base + one 32-bit lane offset, clamped to the last row instead of predicated) are issued before the MFMAs and
-// written after them; the last key tile, the only one with padded keys, is peeled off the loop.  The row maximum is
-// taken per LANE (v_max3 chain); the exchange across a query's four lanes only runs when m_run has to move.  The two
-// MFMA phases run at s_setprio 1 so that the other resident waves' softmax VALU fills their issue gaps.
-// qkv is the fused projection output [rows][1152] bf16 with q pre-scaled by log2(e)/8 in the GEMM epilogue
-// (softmax runs on exp2); out is [rows][384] bf16 with heads concatenated.
+// vit_attn_kernel<MODE>: flash-style, never materialises the N x N scores; MODE = bf16 or IEEE half operands, f32 softmax.
+// qkv is the fused projection output [rows][1152] (16-bit) with q pre-scaled by log2(e)/8 in the GEMM epilogue (softmax
+// runs on exp2); out is [rows][384] with heads concatenated.  Structure and layout notes sit above the kernel.
 // vit_cls_attn_kernel: last block only -- the CLS query against all keys, softmax over N tokens, the CLS
 // column dropped (video_attention.py:56): att [frames][6][N-1] f32.
+#include <stdlib.h>
 #include <type_traits>
 #include "mma.h"
 
@@ -30,18 +18,29 @@
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vit_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok,
-                                                       int ld_qkv, int ld_out, int dim, int heads, int qblocks,
-                                                       int ngroups) {
+// Workgroup = 128 query rows of one (frame, head), 4 waves x 32 rows, on v_mfma_f32_32x32x16_{bf16,f16}.  (Round 1 ran the
+// same algorithm on the 16x16x32 form; both take the same time on MI355X, random data 758 us / zeros 599 us per launch at
+// 512 frames x 785 tokens -- the loop is not bound by the MFMA issue hold, DESIGN.md 9 -- this form needs 10 fewer VGPRs and
+// halves the MFMA instruction count.)  Per 64-key tile and wave:
+//   S^T[64 keys x 32 q] = K Q^T : 2 key blocks x 4 d-steps of 32x32x16, K = A operand (ds_read_b128, chunk ^ ((key>>1)&7):
+//                                conflict-free for the b128 lane groups at a 128-B row stride), query on the lane;
+//   softmax: 32 scores per lane (the query's other 32 keys sit on lane ^ 32), running maximum folded into the MFMA's C,
+//            deferred rescale (one v_permlane32_swap, only when m_run moves);
+//   O^T[64 d x 32 q] += V^T P^T : the exponentiated accumulator registers 8s..8s+7 of key block kb ARE the B fragment of
+//            k-step 2 kb + s (k slot (h, j) = key 32 kb + 16 s + 8 (j>>2) + 4 h + (j&3)); V^T fragments with the same slot
+//            assignment come from two ds_read_b64_tr_b16 (64-B half of a V row ^= (key>>1)&1: every 32-lane half of a
+//            transposed read covers all 64 banks once).
+// The last key tile runs a single 32-key block when that covers the remaining keys (785 tokens: 17 of 64).
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vit_attn_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int ld_qkv, int ld_out, int dim, int heads, int qblocks,
+    int ngroups) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2][ATT_KT * ATT_D];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[2][ATT_KT * ATT_D];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, gq = lane >> 4;
-  // XCD-aware mapping: the QB query blocks of one (frame, head) share that pair's K/V (200 KB); blocks are dealt
-  // round-robin over the 8 XCDs, so give the QB consecutive slots of ONE XCD to the same (frame, head) -- K/V are
-  // then fetched from HBM once and re-read from that XCD's L2 (measured 4.4 GB -> see profiles/ per launch).
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int group = (slot / qblocks) * 8 + xcd;  // (frame, head) pair index
-  if (group >= ngroups) return;                  // padding blocks of the last round
+  const int group = (slot / qblocks) * 8 + xcd;
+  if (group >= ngroups) return;
   const int qb = slot % qblocks;
   const int head = group % heads, frame = group / heads;
   const int q0 = qb * ATT_QT + wv * 32;
@@ -51,31 +50,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const bf16_t* kbase = qkv + dim + head * ATT_D;
   const bf16_t* vbase = qkv + 2 * dim + head * ATT_D;
 
-  // Q^T fragments (B operand): lane (q = l16, gq) holds Q[q][32 ks + 8 gq .. +7]
-  bf16x8 fq[2][2];
+  // Q^T fragments (B operand): lane (q = r, h) holds Q[q][16 ks + 8 h .. +7]
+  bf16x8 fq[4];
+  {
+    int qr = q0 + r;
+    qr = qr < ntok ? qr : ntok - 1;
+    const bf16_t* qp = qbase + (row0 + qr) * ld_qkv + 8 * h;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int qr = q0 + t * 16 + l16;
-    qr = qr < ntok ? qr : ntok - 1;  // rows past the end are clamped; their results are never stored
-    const bf16_t* qp = qbase + (row0 + qr) * ld_qkv;
-    fq[t][0] = *reinterpret_cast<const bf16x8*>(qp + gq * 8);
-    fq[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32 + gq * 8);
+    for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
-  f32x4 o[2][4];
+  f32x16 o[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {0.f, 0.f}, lrow[2] = {0.f, 0.f};   // the first tile rebases m_run unconditionally
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float mrow = 0.f, lrow = 0.f;
 
-  // staging map: thread -> (key = idx>>3, 16-B chunk c = idx&7) for idx = tid and tid + 256
   uint4 kreg[2], vreg[2];
-  // K / V addresses: a wave-uniform frame base (SGPRs) plus a 32-bit byte offset per thread that advances by one key
-  // tile per iteration (one frame's qkv is ntok * ld_qkv * 2 bytes, far below 4 GB)
   const char* kframe = reinterpret_cast<const char*>(kbase + row0 * ld_qkv);
   const char* vframe = reinterpret_cast<const char*>(vbase + row0 * ld_qkv);
-  // Rows past the sequence end are read from the last real row instead (finite values; their scores are masked and
-  // their probabilities are exactly 0), so the loads need no predicate and the registers no zero fill.
   unsigned ldoff[2], ldmax;
 #pragma unroll
   for (int it = 0; it < 2; ++it) ldoff[it] = (unsigned)((it * 32 + (tid >> 3)) * ld_qkv + (tid & 7) * 8) * 2u;
@@ -94,131 +87,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int idx = it * 256 + tid, key = idx >> 3, c = idx & 7;
-      *reinterpret_cast<uint4*>(&Ks[buf][key * ATT_D + ((c ^ (key & 7)) * 8)]) = kreg[it];
-      *reinterpret_cast<uint4*>(&Vs[buf][key * ATT_D + (((c >> 1) ^ ((key >> 1) & 3)) * 16) + (c & 1) * 8]) = vreg[it];
+      *reinterpret_cast<uint4*>(&Ks[buf][key * ATT_D + ((c ^ ((key >> 1) & 7)) * 8)]) = kreg[it];
+      *reinterpret_cast<uint4*>(&Vs[buf][key * ATT_D + (((c >> 2) ^ ((key >> 1) & 1)) * 32) + (c & 3) * 8]) = vreg[it];
     }
   };
+  // per-lane LDS element offsets; key block / k-step / buffer displacements are compile-time or wave-uniform
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * ATT_D + (((2 * ks + h) ^ ((r >> 1) & 7)) * 8);
+  const int i16 = lane & 15, g2 = (lane >> 4) & 1, xb = (i16 >> 3) & 1;
+  const int vrow = (4 * h + (i16 >> 2)) * ATT_D + 16 * g2 + 4 * (i16 & 3);
+  const int voff[2] = {vrow + xb * 32, vrow + (1 ^ xb) * 32};
 
   const int ntiles = (ntok + ATT_KT - 1) / ATT_KT;
+  const bool last_half = ntok - (ntiles - 1) * ATT_KT <= 32;   // the last tile's keys fit one 32-key block
   load_tile();
   store_tile(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Q fragments too, so that no wait on them lands inside the loop
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  // one key tile of this wave's 32 queries; `last_c` = the final tile (the only one that can hold padded keys)
-  auto tile = [&](int kt, auto last_c) __attribute__((always_inline)) {
+  // volatile: keeps the chain behind the wait-state asm above (volatile asm statements are not reordered among themselves)
+  auto max3 = [](float a, float b, float c) __attribute__((always_inline)) {
+    float d;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+  };
+  auto tile = [&](int kt, auto last_c, auto nkb_c) __attribute__((always_inline)) {
+    constexpr int NKB = decltype(nkb_c)::value;
     const int buf = kt & 1, kv0 = kt * ATT_KT;
+    const bf16_t* kt_base = &Ks[buf][0];
+    const bf16_t* vt_base = &Vs[buf][0];
     __builtin_amdgcn_s_setprio(1);
-    // ---- S^T = K Q^T : s[t][nt][r] = score(key 16 nt + 4 gq + r, query t*16 + l16)
-    // The running row maximum goes in as the MFMA's C operand (s' = score - m_run), so no subtraction pass.
-    f32x4 s[2][4];
+    f32x16 s[NKB];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      s[0][nt] = f32x4{-mrow[0], -mrow[0], -mrow[0], -mrow[0]};
-      s[1][nt] = f32x4{-mrow[1], -mrow[1], -mrow[1], -mrow[1]};
-      const int key = nt * 16 + l16;
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&Ks[buf][key * ATT_D + (((ks * 4 + gq) ^ (key & 7)) * 8)]);
-        Mma<MODE_BF16>::mma(s[0][nt], fk, fq[0][ks]);
-        Mma<MODE_BF16>::mma(s[1][nt], fk, fq[1][ks]);
+      for (int e = 0; e < 16; ++e) s[kb][e] = -mrow;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kt_base + kb * 32 * ATT_D + koff[ks]);
+        Mma32<MODE>::mma(s[kb], fk, fq[ks]);
       }
     }
-    if (decltype(last_c)::value && kv0 + ATT_KT > ntok) {  // last, partial tile: mask the padded keys
+    if (decltype(last_c)::value && kv0 + NKB * 32 > ntok) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kv0 + nt * 16 + gq * 4 + r >= ntok) { s[0][nt][r] = -1e30f; s[1][nt][r] = -1e30f; }
+        for (int e = 0; e < 16; ++e)
+          if (kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= ntok) s[kb][e] = -1e30f;
     }
     __builtin_amdgcn_s_setprio(0);
-    // ---- online softmax (base 2), query on the lane
-    // Deferred rescale: m_run only moves when the tile maximum exceeds it by more than ATT_THR (then P <= 2^ATT_THR,
-    // harmless in f32 / bf16); the O / l rescale is a rare wave-uniform branch instead of 32 multiplies per tile.
-    bf16x8 fp[2][2];
-    float mx[2];
+    // ---- online softmax (base 2), query on the lane; this lane's NKB * 16 keys
+    // hipcc's hazard recogniser does not look inside asm statements: the v_max3 chain below reads MFMA results, so the
+    // wait states between an XDL write and a VALU read of the same registers (up to 18 for the 16-pass form) are spent here
+    // explicitly -- without them the last k-step's contribution is missing from some maxima (no fault: a missed rescale,
+    // i.e. P up to 2^31 -- invisible in bf16, infinite in IEEE half).
+    if constexpr (NKB == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
+    else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0]));
+    float mx;
+    {
+      float a[NKB][5];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // 16 scores per lane and query: eight v_max3_f32 (three inputs per instruction; written as asm so that hipcc does
-      // not put a canonicalising v_max in front of every MFMA output)
-      auto max3 = [](float a, float b, float c) __attribute__((always_inline)) {
-        float d;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-        return d;
-      };
-      const float a0 = max3(s[t][0][0], s[t][0][1], s[t][0][2]), a1 = max3(s[t][0][3], s[t][1][0], s[t][1][1]);
-      const float a2 = max3(s[t][1][2], s[t][1][3], s[t][2][0]), a3 = max3(s[t][2][1], s[t][2][2], s[t][2][3]);
-      const float a4 = max3(s[t][3][0], s[t][3][1], s[t][3][2]);
-      mx[t] = max3(max3(a0, a1, a2), a3, max3(a4, s[t][3][3], s[t][3][3]));   // this lane's 16 keys only
+      for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 5; ++g) a[kb][g] = max3(s[kb][3 * g], s[kb][3 * g + 1], s[kb][3 * g + 2]);
+        a[kb][0] = max3(a[kb][0], a[kb][1], s[kb][15]);
+        a[kb][2] = max3(a[kb][2], a[kb][3], a[kb][4]);
+      }
+      if constexpr (NKB == 2) mx = max3(max3(a[0][0], a[0][2], a[1][0]), a[1][2], a[1][2]);
+      else mx = max3(a[0][0], a[0][2], a[0][2]);
     }
     const bool first = kt == 0;
-    // The maximum over a query's four lanes is only needed when m_run moves: some lane exceeding the threshold is the
-    // same condition as some query exceeding it, so the steady state pays no cross-lane exchange at all.
-    if (__any(first || mx[0] > ATT_THR || mx[1] > ATT_THR)) {
-      mx[0] = rows4_max(mx[0]);
-      mx[1] = rows4_max(mx[1]);
+    if (__any(first || mx > ATT_THR)) {
+      float ma, mb;
+      lane_swap32(mx, ma, mb);
+      mx = fmaxf(ma, mb);
+      const float delta = (first || mx > ATT_THR) ? mx : 0.f;
+      const float alpha = fast_exp2(-delta);
+      mrow += delta;
+      lrow *= alpha;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float delta = (first || mx[t] > ATT_THR) ? mx[t] : 0.f;   // first tile: rebase in either direction
-        const float alpha = fast_exp2(-delta);
-        mrow[t] += delta;
-        lrow[t] *= alpha;
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[t][d][r] *= alpha;
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[t][nt][r] -= delta;
-      }
+        for (int e = 0; e < 16; ++e) s[kb][e] -= delta;
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    bf16x8 fp[NKB][2];
+    {
       float sum = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[t][nt][r]);
-          s[t][nt][r] = p;
+        for (int e = 0; e < 16; ++e) {
+          const float p = fast_exp2(s[kb][e]);
+          s[kb][e] = p;
           sum += p;
         }
-      lrow[t] += sum;  // per-lane partial; the 4 lanes of a query are summed at the end
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const unsigned w0 = pack_bf2(s[t][2 * ks][0], s[t][2 * ks][1]), w1 = pack_bf2(s[t][2 * ks][2], s[t][2 * ks][3]);
-        const unsigned w2 = pack_bf2(s[t][2 * ks + 1][0], s[t][2 * ks + 1][1]), w3 = pack_bf2(s[t][2 * ks + 1][2], s[t][2 * ks + 1][3]);
-        const uint4 u = make_uint4(w0, w1, w2, w3);
-        fp[t][ks] = __builtin_bit_cast(bf16x8, u);
+        for (int sx = 0; sx < 2; ++sx) {
+          const uint4 u = make_uint4(pack2<MODE>(s[kb][8 * sx], s[kb][8 * sx + 1]), pack2<MODE>(s[kb][8 * sx + 2], s[kb][8 * sx + 3]),
+                                     pack2<MODE>(s[kb][8 * sx + 4], s[kb][8 * sx + 5]), pack2<MODE>(s[kb][8 * sx + 6], s[kb][8 * sx + 7]));
+          fp[kb][sx] = __builtin_bit_cast(bf16x8, u);
+        }
       }
+      lrow += sum;
     }
     __builtin_amdgcn_s_setprio(1);
-    // ---- O^T += V^T P^T : o[t][dt][r] = O(query t*16 + l16, d = 16 dt + 4 gq + r)
+    // ---- O^T += V^T P^T
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 h[2];
+      for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int key = ks * 32 + hh * 16 + gq * 4 + (l16 >> 2);
-          const bf16_t* a = &Vs[buf][key * ATT_D + ((dt ^ ((key >> 1) & 3)) * 16) + (l16 & 3) * 4];
-          h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+        for (int db = 0; db < 2; ++db) {
+          const bf16_t* a0 = vt_base + (kb * 32 + sx * 16) * ATT_D + voff[db];
+          const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+          const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * ATT_D));
+          Mma32<MODE>::mma(o[db], concat4(h0, h1), fp[kb][sx]);
         }
-        const bf16x8 fv = concat4(h[0], h[1]);
-        Mma<MODE_BF16>::mma(o[0][dt], fv, fp[0][ks]);
-        Mma<MODE_BF16>::mma(o[1][dt], fv, fp[1][ks]);
-      }
     __builtin_amdgcn_s_setprio(0);
   };
-  // A wave whose 32 query rows all lie past the sequence end (ntok = 785: three of the four waves of the last query
-  // block, 11 % of all waves) only helps staging K / V: its MFMA and softmax issue slots go to the other workgroups
-  // resident on the SIMD.
   for (int kt = 0; kt < ntiles - 1; ++kt) {
     load_tile();
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: their latency is covered by the tile's MFMAs
-    if (wave_active) tile(kt, std::false_type{});
-    // the LDS writes stay below the tile's MFMAs (hipcc otherwise merges them into the load block above)
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_active) tile(kt, std::false_type{}, std::integral_constant<int, 2>{});
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       asm volatile("" : "+v"(kreg[it].x), "+v"(kreg[it].y), "+v"(kreg[it].z), "+v"(kreg[it].w));
@@ -227,28 +221,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     store_tile((kt & 1) ^ 1);
     __syncthreads();
   }
-  if (wave_active) tile(ntiles - 1, std::true_type{});
-  // ---- normalise and store: lane holds d = 16 dt + 4 gq + (0..3) of its query
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float l = lrow[t];
-    l = rows4_sum(l);
-    const float inv = 1.f / l;
-    const int qr = q0 + t * 16 + l16;
+  if (wave_active) {
+    if (last_half) tile(ntiles - 1, std::true_type{}, std::integral_constant<int, 1>{});
+    else tile(ntiles - 1, std::true_type{}, std::integral_constant<int, 2>{});
+  }
+  // ---- normalise and store: lane (q = r, h) holds d = 32 db + 8 g + 4 h + (0..3) in registers 4g..4g+3 of o[db]
+  {
+    float la, lb;
+    lane_swap32(lrow, la, lb);
+    const float inv = 1.f / (la + lb);
+    const int qr = q0 + r;
     if (qr < ntok) {
-      bf16_t* op = out + (row0 + qr) * ld_out + head * ATT_D + gq * 4;
+      bf16_t* op = out + (row0 + qr) * ld_out + head * ATT_D + 4 * h;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 u;
-        u.x = pack_bf2(o[t][dt][0] * inv, o[t][dt][1] * inv);
-        u.y = pack_bf2(o[t][dt][2] * inv, o[t][dt][3] * inv);
-        *reinterpret_cast<uint2*>(op + dt * 16) = u;
-      }
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = pack2<MODE>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          u.y = pack2<MODE>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(op + 32 * db + 8 * g) = u;
+        }
     }
   }
 }
 
 // one block per (frame, head): scores of the CLS query against all tokens (q pre-scaled by log2(e)/8 -> exp2)
+template <int MODE>
 __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ att, int ntok,
                                                            int ld_qkv, int dim) {
   extern __shared__ float sc[];  // [ntok]
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restr
   __shared__ float red[4];
   const int tid = threadIdx.x, head = blockIdx.x, frame = blockIdx.y;
   const int64_t row0 = (int64_t)frame * ntok;
-  if (tid < ATT_D) qv[tid] = bf2f(qkv[row0 * ld_qkv + head * ATT_D + tid]);
+  if (tid < ATT_D) qv[tid] = up16<MODE>(qkv[row0 * ld_qkv + head * ATT_D + tid]);
   __syncthreads();
   float mx = -1e30f;
   for (int j = tid; j < ntok; j += 256) {
@@ -268,8 +267,8 @@ __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restr
       const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc = fmaf(__uint_as_float(w[e] << 16), qv[c * 8 + 2 * e], acc);
-        acc = fmaf(__uint_as_float(w[e] & 0xffff0000u), qv[c * 8 + 2 * e + 1], acc);
+        acc = fmaf(up16<MODE>((unsigned short)(w[e] & 0xffffu)), qv[c * 8 + 2 * e], acc);
+        acc = fmaf(up16<MODE>((unsigned short)(w[e] >> 16)), qv[c * 8 + 2 * e + 1], acc);
       }
     }
     sc[j] = acc;
@@ -294,24 +293,35 @@ __global__ __launch_bounds__(256) void vit_cls_attn_kernel(const bf16_t* __restr
   for (int j = tid + 1; j < ntok; j += 256) ap[j - 1] = sc[j] * inv;
 }
 
-extern "C" int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out,
+extern "C" int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
                                void* stream) {
   MAAVSS_CHECK_ARG(qkv && out && frames > 0 && ntok > 0, "vit_attn: bad arguments");
   MAAVSS_CHECK_ARG(heads >= 1 && ld_qkv >= 3 * heads * ATT_D && ld_out >= heads * ATT_D && ld_qkv % 8 == 0 && ld_out % 4 == 0,
                    "vit_attn: bad layout");
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_attn: dtype must be 0 (bf16) or 2 (f16)");
   const int qblocks = cdiv(ntok, ATT_QT), ngroups = frames * heads;
   const int nblocks = cdiv(ngroups, 8) * 8 * qblocks;
-  hipLaunchKernelGGL(vit_attn_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, ntok,
-                     ld_qkv, ld_out, heads * ATT_D, heads, qblocks, ngroups);
+  const bf16_t* q = (const bf16_t*)qkv;
+  bf16_t* o = (bf16_t*)out;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MODE_F16)
+    hipLaunchKernelGGL(vit_attn_kernel<MODE_F16>, dim3(nblocks), dim3(256), 0, st, q, o, ntok, ld_qkv, ld_out, heads * ATT_D, heads, qblocks, ngroups);
+  else
+    hipLaunchKernelGGL(vit_attn_kernel<MODE_BF16>, dim3(nblocks), dim3(256), 0, st, q, o, ntok, ld_qkv, ld_out, heads * ATT_D, heads, qblocks, ngroups);
   MAAVSS_LAUNCH_CHECK("vit_attn_kernel");
   return MAAVSS_OK;
 }
 
-extern "C" int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, void* stream) {
+extern "C" int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream) {
   MAAVSS_CHECK_ARG(qkv && att && frames > 0 && ntok > 1, "vit_cls_attn: bad arguments");
   MAAVSS_CHECK_ARG((size_t)ntok * 4 <= 60 * 1024, "vit_cls_attn: too many tokens for the LDS score buffer");
-  hipLaunchKernelGGL(vit_cls_attn_kernel, dim3(heads, frames), dim3(256), ntok * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)qkv, att, ntok, ld_qkv, heads * ATT_D);
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_cls_attn: dtype must be 0 (bf16) or 2 (f16)");
+  if (dtype == MODE_F16)
+    hipLaunchKernelGGL(vit_cls_attn_kernel<MODE_F16>, dim3(heads, frames), dim3(256), ntok * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)qkv, att, ntok, ld_qkv, heads * ATT_D);
+  else
+    hipLaunchKernelGGL(vit_cls_attn_kernel<MODE_BF16>, dim3(heads, frames), dim3(256), ntok * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)qkv, att, ntok, ld_qkv, heads * ATT_D);
   MAAVSS_LAUNCH_CHECK("vit_cls_attn_kernel");
   return MAAVSS_OK;
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * (1.f + erf_v);
 }
 
-template <int EPI>
+template <int EPI, int MODE>
 __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);  // ring: [3 slots][A 256x64 | B 128x64] bf16 = 144 KiB
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Mma<MODE_BF16>::mma(acc[i][j], fa[i], fb[j]);
+      for (int j = 0; j < 4; ++j) Mma<MODE>::mma(acc[i][j], fa[i], fb[j]);
   };
 #define VG_USE_FRAGS(fa, fb)                 \
   __builtin_amdgcn_sched_barrier(0);         \
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
                   float val = acc[i][j][r] + bv;
                   if constexpr (EPI == EPI_BF16_BIAS_GELU) val = gelu_erf(val);
                   else val *= sc;
-                  cs[((wm & 1) * 64 + i * 16 + gq * 4 + r) * LDC + nl] = f2bf(val);
+                  cs[((wm & 1) * 64 + i * 16 + gq * 4 + r) * LDC + nl] = cvt16<MODE>(val);
                 }
             }
           }
@@ -335,13 +335,14 @@ __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
 
 extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const float* bias, const float* table, int period,
                                void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
-                               void* stream) {
+                               int dtype, void* stream) {
   MAAVSS_CHECK_ARG(A && W && C && M > 0, "vit_gemm: bad arguments");
   MAAVSS_CHECK_ARG(N % VG_BN == 0 && K % VG_BK == 0 && K >= VG_BK, "vit_gemm: N must be a multiple of 128 and K of 64 (N=%d K=%d)", N, K);
   MAAVSS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0, "vit_gemm: leading dimensions must be multiples of 8");
   MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "vit_gemm: unknown epilogue");
   MAAVSS_CHECK_ARG(epilogue == EPI_F32_ROWTABLE ? (table && period > 0) : (bias != nullptr), "vit_gemm: missing bias/table");
   MAAVSS_CHECK_ARG(M < (1LL << 31), "vit_gemm: M too large");
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_gemm: dtype must be 0 (bf16) or 2 (f16)");
   VGemmArgs g;
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.table = table; g.C = C;
   g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.period = period;
@@ -352,21 +353,22 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   nblocks = nblocks >= 256 ? 256 : cdiv(nblocks, 8) * 8;
   const dim3 grid(nblocks), block(VG_THREADS);
   const size_t smem = VG_STAGES * VG_STAGE_ELEMS * sizeof(bf16_t);   // 144 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_BF16_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_BF16_BIAS_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_F32_BIAS_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<EPI_F32_ROWTABLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
   hipStream_t st = (hipStream_t)stream;
-  switch (epilogue) {
-    case EPI_BF16_BIAS: hipLaunchKernelGGL(vit_gemm_kernel<EPI_BF16_BIAS>, grid, block, smem, st, g); break;
-    case EPI_BF16_BIAS_GELU: hipLaunchKernelGGL(vit_gemm_kernel<EPI_BF16_BIAS_GELU>, grid, block, smem, st, g); break;
-    case EPI_F32_BIAS_RESID: hipLaunchKernelGGL(vit_gemm_kernel<EPI_F32_BIAS_RESID>, grid, block, smem, st, g); break;
-    default: hipLaunchKernelGGL(vit_gemm_kernel<EPI_F32_ROWTABLE>, grid, block, smem, st, g); break;
+  // the attribute is per device and idempotent: set at every launch instead of caching a process-wide flag
+#define VG_LAUNCH2(E, D)                                                                                                       \
+  {                                                                                                                            \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_gemm_kernel<E, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((vit_gemm_kernel<E, D>), grid, block, smem, st, g);                                                     \
   }
+#define VG_LAUNCH(E) { if (dtype == MODE_F16) VG_LAUNCH2(E, MODE_F16) else VG_LAUNCH2(E, MODE_BF16) }
+  switch (epilogue) {
+    case EPI_BF16_BIAS: VG_LAUNCH(EPI_BF16_BIAS) break;
+    case EPI_BF16_BIAS_GELU: VG_LAUNCH(EPI_BF16_BIAS_GELU) break;
+    case EPI_F32_BIAS_RESID: VG_LAUNCH(EPI_F32_BIAS_RESID) break;
+    default: VG_LAUNCH(EPI_F32_ROWTABLE) break;
+  }
+#undef VG_LAUNCH
+#undef VG_LAUNCH2
   MAAVSS_LAUNCH_CHECK("vit_gemm_kernel");
   return MAAVSS_OK;
 }

@@ -7,6 +7,7 @@
 //                     pass 1 per frame: head sum, frame max;  pass 2: clip max, upsampled store.
 #include "common.h"
 
+template <int MODE>
 __global__ __launch_bounds__(256) void vit_patchify_kernel(const float* __restrict__ frames, bf16_t* __restrict__ a, int H,
                                                            int W, int hp, int wp, int64_t total) {
   // one thread = one (row, c, dy): 8 contiguous pixels -> 8 bf16 (16 B)
@@ -21,12 +22,13 @@ __global__ __launch_bounds__(256) void vit_patchify_kernel(const float* __restri
       const int p = tok - 1, py = p / wp, px = p % wp, c = seg >> 3, dy = seg & 7;
       const float* src = frames + ((f * 3 + c) * H + py * 8 + dy) * (int64_t)W + px * 8;
       const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-      o.x = pack_bf2(v0.x, v0.y); o.y = pack_bf2(v0.z, v0.w); o.z = pack_bf2(v1.x, v1.y); o.w = pack_bf2(v1.z, v1.w);
+      o.x = pack2<MODE>(v0.x, v0.y); o.y = pack2<MODE>(v0.z, v0.w); o.z = pack2<MODE>(v1.x, v1.y); o.w = pack2<MODE>(v1.z, v1.w);
     }
     *reinterpret_cast<uint4*>(a + row * 192 + seg * 8) = o;
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             int64_t rows, float eps) {
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = (i * 64 + lane) * 2;
-    yp[i * 64 + lane] = pack_bf2((v[i].x - mean) * rstd * gamma[c] + beta[c], (v[i].y - mean) * rstd * gamma[c + 1] + beta[c + 1]);
+    yp[i * 64 + lane] = pack2<MODE>((v[i].x - mean) * rstd * gamma[c] + beta[c], (v[i].y - mean) * rstd * gamma[c + 1] + beta[c + 1]);
   }
 }
 
@@ -131,23 +133,28 @@ __global__ __launch_bounds__(256) void vit_maps_pass2_kernel(const float* __rest
   }
 }
 
-extern "C" int maavss_vit_patchify(const float* frames, void* a, int64_t n_frames, int H, int W, void* stream) {
+extern "C" int maavss_vit_patchify(const float* frames, void* a, int64_t n_frames, int H, int W, int dtype, void* stream) {
+  MAAVSS_CHECK_ARG(dtype == 0 || dtype == 2, "vit_patchify: dtype must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(frames && a && n_frames > 0, "vit_patchify: bad arguments");
   MAAVSS_CHECK_ARG(H >= 8 && W >= 8 && W % 4 == 0, "vit_patchify: frame must be at least 8x8 with W a multiple of 4");
   const int hp = H / 8, wp = W / 8;
   const int64_t total = n_frames * (hp * wp + 1) * 24;
-  hipLaunchKernelGGL(vit_patchify_kernel, dim3((unsigned)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, frames, (bf16_t*)a, H, W, hp, wp, total);
+  const dim3 grid((unsigned)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256));
+  if (dtype == 2) hipLaunchKernelGGL(vit_patchify_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, frames, (bf16_t*)a, H, W, hp, wp, total);
+  else hipLaunchKernelGGL(vit_patchify_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, frames, (bf16_t*)a, H, W, hp, wp, total);
   MAAVSS_LAUNCH_CHECK("vit_patchify_kernel");
   return MAAVSS_OK;
 }
 
 extern "C" int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, void* y, int64_t rows, int dim,
-                                    float eps, void* stream) {
+                                    float eps, int dtype, void* stream) {
   MAAVSS_CHECK_ARG(x && gamma && beta && y && rows > 0, "vit_layernorm: bad arguments");
+  MAAVSS_CHECK_ARG(dtype == 0 || dtype == 2, "vit_layernorm: dtype must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(dim == 384, "vit_layernorm: only dim 384 (ViT-S) is built");
-  hipLaunchKernelGGL(vit_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                     (bf16_t*)y, rows, eps);
+  if (dtype == 2)
+    hipLaunchKernelGGL(vit_layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y, rows, eps);
+  else
+    hipLaunchKernelGGL(vit_layernorm_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y, rows, eps);
   MAAVSS_LAUNCH_CHECK("vit_layernorm_kernel");
   return MAAVSS_OK;
 }

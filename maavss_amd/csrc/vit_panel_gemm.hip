@@ -81,7 +81,7 @@ __device__ __forceinline__ int panel_off(int r, int k) {
 // lanes >= 32 row B [4(l-32), +4); j = 2: row B [128 + 4l, +4)): half the vector-memory instructions of an 8-byte-per-lane
 // sweep (the issue of 42 such loads per wave, twelve waves at once, was stamped at 8-13 k cycles per panel).  All 3 NP
 // loads go out before the first reduction, so the wave pays ONE memory latency.
-template <int NP>
+template <int NP, int MODE>
 __device__ __forceinline__ void pg_ln_rows(const PGemmArgs& g, bf16_t* panel, int m0, int r0, int lane) {
   const bool lo = lane < 32;
   const int kj[3] = {4 * lane, lo ? 256 + 4 * lane : 4 * (lane - 32), 128 + 4 * lane};
@@ -122,14 +122,14 @@ __device__ __forceinline__ void pg_ln_rows(const PGemmArgs& g, bf16_t* panel, in
     const int row[3] = {r0 + 2 * pp, r0 + 2 * pp + (lo ? 0 : 1), r0 + 2 * pp + 1};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const uint2 o = make_uint2(pack_bf2(c[j].x * rstd[j] * gam[j].x + bet[j].x, c[j].y * rstd[j] * gam[j].y + bet[j].y),
-                                 pack_bf2(c[j].z * rstd[j] * gam[j].z + bet[j].z, c[j].w * rstd[j] * gam[j].w + bet[j].w));
+      const uint2 o = make_uint2(pack2<MODE>(c[j].x * rstd[j] * gam[j].x + bet[j].x, c[j].y * rstd[j] * gam[j].y + bet[j].y),
+                                 pack2<MODE>(c[j].z * rstd[j] * gam[j].z + bet[j].z, c[j].w * rstd[j] * gam[j].w + bet[j].w));
       *reinterpret_cast<uint2*>(panel + panel_off(row[j], kj[j])) = o;
     }
   }
 }
 
-template <int EPI, bool FUSE_LN>
+template <int EPI, bool FUSE_LN, int MODE>
 __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* panel = reinterpret_cast<bf16_t*>(smem);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
     for (int pp = 0; pp < 3; ++pp)
       if (pp < total_pairs) { stage(2 * pp); stage(2 * pp + 1); }
     if constexpr (FUSE_LN) {
-      pg_ln_rows<2>(g, panel, m0, 112 + lw * 4, lane);     // its loads retire behind the DMA pieces: everything has landed after it
+      pg_ln_rows<2, MODE>(g, panel, m0, 112 + lw * 4, lane);     // its loads retire behind the DMA pieces: everything has landed after it
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
       if (total_pairs > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
   if constexpr (FUSE_LN) {
     // all twelve waves build the panel, each in a single round of loads: 14 rows per MFMA wave, 4 per loader wave
     // (the loaders first have their 12 ring pieces to issue; stamped, this split lets all waves arrive together)
-    pg_ln_rows<7>(g, panel, m0, wv * 14, lane);
+    pg_ln_rows<7, MODE>(g, panel, m0, wv * 14, lane);
   } else {
     // bf16 input: 8 rows x 128 B per wave-instruction; 16 row-groups x 6 segments = 96 pieces, 12 per wave.  Rows are
     // 768 B apart in the panel, so a lane-linear LDS-DMA destination cannot cover them: staged through registers
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) Mma<MODE_BF16>::mma(acc[a][b], fw[a], fx[b]);
+      for (int b = 0; b < 2; ++b) Mma<MODE>::mma(acc[a][b], fw[a], fx[b]);
   };
 #define PG_USE(fw, fx)               \
   __builtin_amdgcn_sched_barrier(0); \
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * g.qscale;
       }
-      const uint4 o = make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
+      const uint4 o = make_uint4(pack2<MODE>(v[0].x, v[0].y), pack2<MODE>(v[1].x, v[1].y), pack2<MODE>(v[2].x, v[2].y), pack2<MODE>(v[3].x, v[3].y));
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (int64_t)m * g.ldc + n) = o;
     }
   };
@@ -338,11 +338,12 @@ __global__ __launch_bounds__(PG_THREADS) void vit_panel_gemm_kernel(PGemmArgs g)
 
 extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
                                      float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows,
-                                     int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* stream) {
+                                     int64_t M, int N, int epilogue, int qscale_cols, float qscale, int dtype, void* stream) {
   MAAVSS_CHECK_ARG((X != nullptr) != (A != nullptr), "vit_panel_gemm: exactly one of X (f32, LayerNorm fused) and A (bf16) must be given");
   MAAVSS_CHECK_ARG(W && bias && C && M > 0 && M < (1LL << 31), "vit_panel_gemm: bad arguments");
   MAAVSS_CHECK_ARG(N % PG_BN == 0 && N >= PG_BN, "vit_panel_gemm: N must be a multiple of 128 (got %d)", N);
   MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "vit_panel_gemm: unknown epilogue");
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_panel_gemm: dtype must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(!X || (ln_gamma && ln_beta), "vit_panel_gemm: LayerNorm parameters missing");
   MAAVSS_CHECK_ARG(X || (lda % 8 == 0 && lda >= PG_K), "vit_panel_gemm: lda must be a multiple of 8 and >= 384");
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && qscale_cols % 8 == 0, "vit_panel_gemm: ldc / qscale_cols must be multiples of 8");
@@ -354,13 +355,16 @@ extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, con
   g.qscale_cols = qscale_cols; g.qscale = qscale; g.panels = cdiv(M, PG_BM);
   const size_t smem = (PG_PANEL_ELEMS + PG_STAGES * PG_BTILE_ELEMS) * sizeof(bf16_t);   // 96 + 64 = 160 KiB: all of a CU's LDS
   hipStream_t st = (hipStream_t)stream;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
+  // one process drives one GPU, but the CU count is still looked up per device
+  static int n_cu_dev[64] = {0};
+  int dev = 0;
+  MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "vit_panel_gemm: cannot query the device");
+  if (!n_cu_dev[dev]) {
     hipDeviceProp_t prop;
-    MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess, "vit_panel_gemm: cannot query the device");
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    MAAVSS_CHECK_ARG(hipGetDeviceProperties(&prop, dev) == hipSuccess, "vit_panel_gemm: cannot query the device");
+    n_cu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  const int n_cu = n_cu_dev[dev];
   const int tail = g.panels % n_cu;        // one workgroup per CU (160 KiB of LDS): panels run in rounds of n_cu
   g.full = g.panels - tail;
   g.split = 1;
@@ -370,20 +374,19 @@ extern "C" int maavss_vit_panel_gemm(const float* X, const void* A, int lda, con
     if (g.split < 1) g.split = 1;
   }
   const dim3 grid(g.full + tail * g.split), block(PG_THREADS);
-#define PG_LAUNCH(E, L)                                                                                              \
+  // hipFuncSetAttribute is per device and idempotent: set it at every launch (a few hundred ns) rather than cache a flag
+#define PG_LAUNCH3(E, L, D)                                                                                          \
   {                                                                                                                  \
-    static bool set = false;                                                                                         \
-    if (!set) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(vit_panel_gemm_kernel<E, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-      set = true;                                                                                                    \
-    }                                                                                                                \
-    hipLaunchKernelGGL((vit_panel_gemm_kernel<E, L>), grid, block, smem, st, g);                                     \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_panel_gemm_kernel<E, L, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((vit_panel_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                  \
   }
+#define PG_LAUNCH(E, L) { if (dtype == MODE_F16) PG_LAUNCH3(E, L, MODE_F16) else PG_LAUNCH3(E, L, MODE_BF16) }
   if (X) {
     if (epilogue == 0) PG_LAUNCH(0, true) else if (epilogue == 1) PG_LAUNCH(1, true) else PG_LAUNCH(2, true)
   } else {
     if (epilogue == 0) PG_LAUNCH(0, false) else if (epilogue == 1) PG_LAUNCH(1, false) else PG_LAUNCH(2, false)
   }
+#undef PG_LAUNCH3
 #undef PG_LAUNCH
   MAAVSS_LAUNCH_CHECK("vit_panel_gemm_kernel");
   return MAAVSS_OK;

@@ -116,12 +116,40 @@ def plan_stft_decoder(t_a, n_bins, t_v, s_v, latent, c_stft=2):
     return plan
 
 
+class _Conv3d16bit(torch.autograd.Function):
+    """Conv3d whose operands are rounded where the HIP 16-bit path rounds them (maavss_amd/avse.py, precise=False):
+    forward x and w to IEEE half, backward dy / w (input gradient) and dy / x (weight gradient) to bf16; products and
+    sums in f32.  What remains between this and the kernels is summation order."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad):
+        ctx.save_for_backward(x, w)
+        ctx.pad = pad
+        return F.conv3d(x.half().float(), w.half().float(), padding=(1, pad, pad))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        bf = lambda t: t.to(torch.bfloat16).float()     # noqa: E731
+        dyb, pad = bf(dy), (1, ctx.pad, ctx.pad)
+        dx = torch.nn.grad.conv3d_input(x.shape, bf(w), dyb, padding=pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv3d_weight(bf(x), w.shape, dyb, padding=pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class _Conv3dEmu(nn.Conv3d):
+    def forward(self, x):
+        return _Conv3d16bit.apply(x, self.weight, self.padding[1])
+
+
 class AVFusionFramesRef(nn.Module):
     """Oracle twin of the reference's AV_Fusion_Model_Frames (same ctor args,
-    same forward contract, same state_dict keys)."""
+    same forward contract, same state_dict keys).  `emulate_16bit=True` (not in the reference) rounds the operands
+    of the four C_in > 1 Conv3d layers like the HIP path's default 16-bit mode does -- used to separate quantisation
+    error (vs this class with emulate_16bit=False, the pinned fp32 oracle) from implementation error."""
 
     def __init__(self, stft_shape, frame_shape, hops_per_frame, latent_channels=16, fc_size=4096,
-                 spatial_match="exact"):
+                 spatial_match="exact", emulate_16bit=False):
         super().__init__()
         self.stft_shape = list(stft_shape)
         self.frame_shape = list(frame_shape)
@@ -140,7 +168,8 @@ class AVFusionFramesRef(nn.Module):
         pads = [2, 2, 2, 2, 3]
         mods = []
         for i in range(5):
-            mods += [nn.Conv3d(chans[i], chans[i + 1], (3, 5, 5), 1, (1, pads[i], pads[i]), bias=False),
+            conv = _Conv3dEmu if (emulate_16bit and i > 0) else nn.Conv3d     # layer 0 (C_in = 1) runs in f32 on the GPU too
+            mods += [conv(chans[i], chans[i + 1], (3, 5, 5), 1, (1, pads[i], pads[i]), bias=False),
                      nn.BatchNorm3d(chans[i + 1]),
                      nn.MaxPool3d((1, pools[i], pools[i])),
                      nn.LeakyReLU()]

@@ -79,15 +79,22 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
     return torch.cat([pos_embed[:, :1], patch], 1)
 
 
-def _bf(x):
-    """round to bf16 (nearest even) and return as f32 -- the storage rounding of the HIP path"""
-    return x.to(torch.bfloat16).float()
+_ROUND = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
-def prepare_tokens(sd, frames, emulate_bf16=False):
+def _rounder(emulate):
+    """emulate: None / False = fp32; "bf16" / "f16" (True = "bf16") = round to that storage format and return f32"""
+    if not emulate:
+        return lambda t: t
+    dt = _ROUND["bf16" if emulate is True else emulate]
+    return lambda t: t.to(dt).float()
+
+
+def prepare_tokens(sd, frames, emulate=None):
     b, _, h, w = frames.shape
-    if emulate_bf16:      # vit_patchify stores bf16 patches, the weight is bf16; bias + cls + pos stay f32 (row table)
-        x = F.conv2d(_bf(frames), _bf(sd["patch_embed.proj.weight"]), None, stride=PATCH) + sd["patch_embed.proj.bias"][None, :, None, None]
+    r = _rounder(emulate)
+    if emulate:      # vit_patchify stores 16-bit patches, the weight is 16-bit; bias + cls + pos stay f32 (row table)
+        x = F.conv2d(r(frames), r(sd["patch_embed.proj.weight"]), None, stride=PATCH) + sd["patch_embed.proj.bias"][None, :, None, None]
     else:
         x = F.conv2d(frames, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=PATCH)
     x = x.flatten(2).transpose(1, 2)
@@ -96,31 +103,67 @@ def prepare_tokens(sd, frames, emulate_bf16=False):
 
 
 QSCALE = 0.125 * 1.4426950408889634      # log2(e) / sqrt(64): the kernels run softmax on exp2
+ATT_KT, ATT_THR = 64, 5.0                # key tile and deferred-rescale threshold of maavss_amd/csrc/vit_attn.hip
+_GELU_C = (-9.018102001e-10, 7.941707090e-08, -3.038026629e-06, 6.689195681e-05, -9.506666631e-04, 9.298265605e-03,
+           -6.552827696e-02, 3.984659427e-01)
 
 
-def block_forward(sd, i, x, return_attention=False, emulate_bf16=False):
-    """One pre-LN block.  `emulate_bf16` rounds exactly where the HIP kernels store 16-bit values: the
-    weights, the LayerNorm output, q (after the log2(e)/8 scale) / k / v, the exponentiated probabilities that enter
-    P.V (the row sum keeps the unrounded f32 values), the attention output and the GELU output; accumulation, biases,
-    residual stream and softmax stay f32.  What is left between this and the kernels is summation order, the deferred
-    running-maximum of the online softmax and the polynomial GELU (|err| < 1e-4)."""
+def gelu_poly(v):
+    """the panel GEMM's GELU (vit_panel_gemm.hip pg_gelu4): v * (1/2 + c Q(c^2)), c = clamp(v, +-4.2), Q a degree-7
+    minimax polynomial; |error| vs the exact-erf GELU < 1e-4 -- comparable to the rounding step of small outputs, so the
+    emulation has to use the same function."""
+    c = v.clamp(-4.2, 4.2)
+    u = c * c
+    q = u * _GELU_C[0] + _GELU_C[1]
+    for k in _GELU_C[2:]:
+        q = q * u + k
+    return v * (c * q + 0.5)
+
+
+def flash_attention_emulated(q, k, v, r):
+    """softmax(q k^T) v of the flash kernel, rounding where it rounds: key tiles of 64 in order, a running maximum that
+    only moves when a tile exceeds it by more than 2^5 (first tile: rebased to its own maximum), P = exp2(s - m) rounded
+    to the 16-bit format for the P.V product while the row sum keeps the f32 values, O rescaled when m moves.
+    q (pre-scaled, log2 units), k, v: [b, heads, n, 64] f32 holding 16-bit-representable values."""
+    n = k.shape[-2]
+    s_all = q @ k.transpose(-2, -1)
+    m = torch.zeros(s_all.shape[:-1] + (1,))
+    l = torch.zeros_like(m)
+    o = torch.zeros(q.shape)
+    for t0 in range(0, n, ATT_KT):
+        s = s_all[..., t0:t0 + ATT_KT] - m
+        mx = s.max(-1, keepdim=True).values
+        delta = torch.where(mx > ATT_THR, mx, torch.zeros_like(mx)) if t0 else mx
+        alpha = torch.exp2(-delta)
+        m = m + delta
+        l, o = l * alpha, o * alpha
+        p = torch.exp2(s - delta)
+        l = l + p.sum(-1, keepdim=True)
+        o = o + r(p) @ v[..., t0:t0 + ATT_KT, :]
+    return o / l
+
+
+def block_forward(sd, i, x, return_attention=False, emulate=None):
+    """One pre-LN block.  `emulate` ("bf16" / "f16") rounds exactly where the HIP kernels store 16-bit values:
+    the weights, the LayerNorm output, q (after the log2(e)/8 scale) / k / v, the exponentiated probabilities that enter
+    P.V (tile-wise, with the kernel's deferred running maximum; the row sum keeps the unrounded f32 values), the attention
+    output and the GELU output (the kernel's polynomial GELU for fc1); accumulation, biases, residual stream and softmax
+    stay f32.  What is left between this and the kernels is summation order and hardware exp2 / rsqrt ulps."""
     p = f"blocks.{i}."
     b, n, _ = x.shape
-    r = _bf if emulate_bf16 else (lambda t: t)
+    r = _rounder(emulate)
     y = r(F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS))
     qkv = F.linear(y, r(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"])
-    if emulate_bf16:
-        qkv = torch.cat([qkv[..., :DIM] * QSCALE, qkv[..., DIM:]], -1)
-        qkv = _bf(qkv)
+    if emulate:
+        qkv = r(torch.cat([qkv[..., :DIM] * QSCALE, qkv[..., DIM:]], -1))
     qkv = qkv.reshape(b, n, 3, HEADS, DIM // HEADS).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    if emulate_bf16:
-        s = q @ k.transpose(-2, -1)                         # log2 units
-        pexp = torch.exp2(s - s.max(-1, keepdim=True).values)
-        if return_attention:
+    if emulate:
+        if return_attention:          # vit_cls_attn: exact row maximum, f32 throughout
+            s = q @ k.transpose(-2, -1)
+            pexp = torch.exp2(s - s.max(-1, keepdim=True).values)
             return pexp / pexp.sum(-1, keepdim=True)
-        y = (_bf(pexp) @ v) / pexp.sum(-1, keepdim=True)
-        y = _bf(y.transpose(1, 2).reshape(b, n, DIM))
+        y = r(flash_attention_emulated(q, k, v, r).transpose(1, 2).reshape(b, n, DIM))
     else:
         att = (q @ k.transpose(-2, -1)) * ((DIM // HEADS) ** -0.5)
         att = att.softmax(-1)
@@ -129,23 +172,24 @@ def block_forward(sd, i, x, return_attention=False, emulate_bf16=False):
         y = (att @ v).transpose(1, 2).reshape(b, n, DIM)
     x = x + F.linear(y, r(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
     y = r(F.layer_norm(x, (DIM,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS))
-    y = r(F.gelu(F.linear(y, r(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])))
+    h = F.linear(y, r(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])
+    y = r(gelu_poly(h)) if emulate else F.gelu(h)
     return x + F.linear(y, r(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
 
 
-def get_last_selfattention(sd, frames, return_hidden=False, emulate_bf16=False):
-    x = prepare_tokens(sd, frames, emulate_bf16)
+def get_last_selfattention(sd, frames, return_hidden=False, emulate=None):
+    x = prepare_tokens(sd, frames, emulate)
     hidden = [x]
     for i in range(DEPTH - 1):
-        x = block_forward(sd, i, x, emulate_bf16=emulate_bf16)
+        x = block_forward(sd, i, x, emulate=emulate)
         hidden.append(x)
-    att = block_forward(sd, DEPTH - 1, x, return_attention=True, emulate_bf16=emulate_bf16)
+    att = block_forward(sd, DEPTH - 1, x, return_attention=True, emulate=emulate)
     return (att, hidden) if return_hidden else att
 
 
-def cls_attention(sd, frames, emulate_bf16=False):
+def cls_attention(sd, frames, emulate=None):
     """[B,3,H,W] -> CLS-row attention without the CLS column, [B, 6, N]."""
-    return get_last_selfattention(sd, frames, emulate_bf16=emulate_bf16)[:, :, 0, 1:]
+    return get_last_selfattention(sd, frames, emulate=emulate)[:, :, 0, 1:]
 
 
 def attention_frames_from_cls(cls_att, h_tok, w_tok):
@@ -158,12 +202,12 @@ def attention_frames_from_cls(cls_att, h_tok, w_tok):
     return a[:, None]
 
 
-def inference_ref(sd, frames, emulate_bf16=False):
+def inference_ref(sd, frames, emulate=None):
     """VideoAttention._inference: frames [T,3,H,W] -> [T,1,H,W] (H, W cropped to multiples of 8 are
     written into a zero canvas of the original size, video_attention.py:39,43-47,96)."""
     t, _, h, w = frames.shape
     hc, wc = h - h % PATCH, w - w % PATCH
-    att = cls_attention(sd, frames[:, :, :hc, :wc], emulate_bf16)
+    att = cls_attention(sd, frames[:, :, :hc, :wc], emulate)
     out = torch.zeros(t, 1, h, w)
     out[:, :, :hc, :wc] = attention_frames_from_cls(att, hc // PATCH, wc // PATCH)
     return out

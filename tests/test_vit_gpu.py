@@ -21,6 +21,13 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
+DT = {0: torch.bfloat16, 2: torch.float16}      # include/maavss.h `dtype`: 0 = bf16, 2 = IEEE half
+
+
+def rd(x, dt):
+    return x.to(DT[dt])
+
+
 def _call(name, *args):
     from maavss_amd import _lib
     _lib.call(name, *args)
@@ -31,30 +38,31 @@ def _st():
     return _lib.stream_ptr()
 
 
+@pytest.mark.parametrize("dt", [0, 2])
 @pytest.mark.parametrize("m,n,k", [(1000, 1152, 384), (785 * 3, 384, 1536), (130, 1536, 384), (197, 384, 192)])
-def test_vit_gemm_epilogues(m, n, k):
-    a, w, bias = bf(rnd(m, k, seed=1)), bf(rnd(n, k, seed=2, scale=k ** -0.5)), rnd(n, seed=3, scale=0.1)
+def test_vit_gemm_epilogues(m, n, k, dt):
+    a, w, bias = rd(rnd(m, k, seed=1), dt), rd(rnd(n, k, seed=2, scale=k ** -0.5), dt), rnd(n, seed=3, scale=0.1)
     z = a.float() @ w.float().t() + bias
     ac, wc, bc = a.cuda(), w.cuda(), bias.cuda()
     # 0: +bias, q-scale on the first 384 columns -> bf16
-    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
-    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 0, 384, 0.125, _st())
+    c = torch.empty(m, n, dtype=DT[dt], device="cuda")
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 0, 384, 0.125, dt, _st())
     want = z.clone()
     want[:, :384] *= 0.125
     np.testing.assert_allclose(c.float().cpu().numpy(), want.numpy(), rtol=1e-2, atol=1e-2)
     # 1: +bias, GELU -> bf16
-    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 1, 0, 1.0, _st())
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, c.data_ptr(), n, m, n, k, 1, 0, 1.0, dt, _st())
     np.testing.assert_allclose(c.float().cpu().numpy(), F.gelu(z).numpy(), rtol=1e-2, atol=1e-2)
     # 2: residual in place, f32
     res = rnd(m, n, seed=4)
     x = res.clone().cuda()
-    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, x.data_ptr(), n, m, n, k, 2, 0, 1.0, _st())
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr(), None, 0, x.data_ptr(), n, m, n, k, 2, 0, 1.0, dt, _st())
     np.testing.assert_allclose(x.cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=2e-4)
     # 3: periodic row table
     period = 197 if m % 197 == 0 else 13
     table = rnd(period, n, seed=5)
     tc = table.cuda()
-    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), None, tc.data_ptr(), period, x.data_ptr(), n, m, n, k, 3, 0, 1.0, _st())
+    _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), None, tc.data_ptr(), period, x.data_ptr(), n, m, n, k, 3, 0, 1.0, dt, _st())
     want = (a.float() @ w.float().t()) + table[torch.arange(m) % period]
     np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
 
@@ -72,7 +80,7 @@ def test_vit_gemm_f32_epilogue_stays_inside_its_rows_and_columns(epi):
     x[:m, :n] = res
     xc, ac, wc, bc, tc = x.cuda(), a.cuda(), w.cuda(), bias.cuda(), table.cuda()
     _call("maavss_vit_gemm", ac.data_ptr(), k, wc.data_ptr(), bc.data_ptr() if epi == 2 else None, tc.data_ptr() if epi == 3 else None,
-          13 if epi == 3 else 0, xc.data_ptr(), ldc, m, n, k, epi, 0, 1.0, _st())
+          13 if epi == 3 else 0, xc.data_ptr(), ldc, m, n, k, epi, 0, 1.0, 0, _st())
     got = xc.cpu()
     z = a.float() @ w.float().t()
     want = res + z + bias if epi == 2 else z + table[torch.arange(m) % 13]
@@ -81,38 +89,39 @@ def test_vit_gemm_f32_epilogue_stays_inside_its_rows_and_columns(epi):
     assert (got[:m, n:] == sentinel).all(), "columns past N were written"
 
 
+@pytest.mark.parametrize("dt", [0, 2])
 @pytest.mark.parametrize("m,n", [(1000, 1152), (785 * 2 + 3, 1536), (130, 384)])
-def test_vit_panel_gemm_fused_layernorm(m, n):
+def test_vit_panel_gemm_fused_layernorm(m, n, dt):
     """LN + GEMM panel kernel (K = 384) against torch: LayerNorm in f32, operands rounded to bf16, f32 accumulate."""
     k = 384
     x = rnd(m, k, seed=1, scale=1.5) + 0.2
     gam, bet = 1 + 0.1 * rnd(k, seed=2), 0.1 * rnd(k, seed=3)
-    w, bias = bf(rnd(n, k, seed=4, scale=k ** -0.5)), rnd(n, seed=5, scale=0.1)
-    xn = bf(F.layer_norm(x, (k,), gam, bet, 1e-6)).float()
+    w, bias = rd(rnd(n, k, seed=4, scale=k ** -0.5), dt), rnd(n, seed=5, scale=0.1)
+    xn = rd(F.layer_norm(x, (k,), gam, bet, 1e-6), dt).float()
     z = xn @ w.float().t() + bias
     xc, gc, bc, wc, biasc = x.cuda(), gam.cuda(), bet.cuda(), w.cuda(), bias.cuda()
     mp = (m + 127) // 128 * 128                       # outputs are allocated in whole 128-row panels
-    c = torch.empty(mp, n, dtype=torch.bfloat16, device="cuda")
+    c = torch.empty(mp, n, dtype=DT[dt], device="cuda")
     _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
-          c.data_ptr(), n, mp, m, n, 0, 384, 0.125, _st())
+          c.data_ptr(), n, mp, m, n, 0, 384, 0.125, dt, _st())
     want = z.clone()
     want[:, :384] *= 0.125
     np.testing.assert_allclose(c[:m].float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
     _call("maavss_vit_panel_gemm", xc.data_ptr(), None, 0, gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
-          c.data_ptr(), n, mp, m, n, 1, 0, 1.0, _st())
+          c.data_ptr(), n, mp, m, n, 1, 0, 1.0, dt, _st())
     np.testing.assert_allclose(c[:m].float().cpu().numpy(), F.gelu(z).numpy(), rtol=1.5e-2, atol=1.5e-2)
     # bf16 input (no LayerNorm), f32 residual in place
-    a = bf(rnd(m, k, seed=6))
+    a = rd(rnd(m, k, seed=6), dt)
     res = rnd(m, n, seed=7)
     ac = a.cuda()
     rc = torch.zeros(mp, n, device="cuda")
     rc[:m] = res.cuda()
     _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, mp,
-          m, n, 2, 0, 1.0, _st())
+          m, n, 2, 0, 1.0, dt, _st())
     np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + a.float() @ w.float().t() + bias).numpy(), rtol=1e-4, atol=3e-4)
     with pytest.raises(Exception):                     # unpadded output is refused
         _call("maavss_vit_panel_gemm", None, ac.data_ptr(), k, None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n,
-              m - 1 if m % 128 == 0 else m, m, n, 2, 0, 1.0, _st())
+              m - 1 if m % 128 == 0 else m, m, n, 2, 0, 1.0, dt, _st())
 
 
 def test_vit_layernorm_and_patchify():
@@ -120,53 +129,66 @@ def test_vit_layernorm_and_patchify():
     x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
     y = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
     xc, gc, bc = x.cuda(), g.cuda(), b.cuda()      # keep the device tensors alive across the call
-    _call("maavss_vit_layernorm", xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), rows, 384, 1e-6, _st())
+    _call("maavss_vit_layernorm", xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), rows, 384, 1e-6, 0, _st())
     want = F.layer_norm(x, (384,), g, b, 1e-6)
     np.testing.assert_allclose(y.float().cpu().numpy(), want.numpy(), rtol=8e-3, atol=8e-3)
     fr = rnd(3, 3, 40, 24, seed=4)
     ntok = 5 * 3 + 1
     a = torch.empty(3 * ntok, 192, dtype=torch.bfloat16, device="cuda")
     frc = fr.cuda()
-    _call("maavss_vit_patchify", frc.data_ptr(), a.data_ptr(), 3, 40, 24, _st())
+    _call("maavss_vit_patchify", frc.data_ptr(), a.data_ptr(), 3, 40, 24, 0, _st())
     want = F.unfold(fr, 8, stride=8).transpose(1, 2)          # [3, 15, 192] in (c, dy, dx) order
     got = a.float().cpu().view(3, ntok, 192)
     assert got[:, 0].abs().max().item() == 0
     np.testing.assert_allclose(got[:, 1:].numpy(), bf(want).float().numpy(), rtol=0, atol=0)
+    ah = torch.empty(3 * ntok, 192, dtype=torch.float16, device="cuda")
+    _call("maavss_vit_patchify", frc.data_ptr(), ah.data_ptr(), 3, 40, 24, 2, _st())
+    np.testing.assert_allclose(ah.float().cpu().view(3, ntok, 192)[:, 1:].numpy(), want.half().float().numpy(), rtol=0, atol=0)
+    yh = torch.empty(rows, 384, dtype=torch.float16, device="cuda")
+    _call("maavss_vit_layernorm", xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), yh.data_ptr(), rows, 384, 1e-6, 2, _st())
+    np.testing.assert_allclose(yh.float().cpu().numpy(), F.layer_norm(x, (384,), g, b, 1e-6).numpy(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("ntok,frames", [(785, 2), (65, 3), (1025, 1)])
-def test_vit_attention_and_cls(ntok, frames):
+@pytest.mark.parametrize("dt", [0, 2])
+@pytest.mark.parametrize("ntok,frames", [(785, 2), (65, 3), (1025, 1), (2305, 1), (97, 2)])
+def test_vit_attention_and_cls(ntok, frames, dt):
+    """ntok 785 / 1025 / 2305 = the 224^2 / 256^2 / 384^2 token counts (BASELINE configs 1-3); 97: last tile of 33 keys
+    (two key blocks), 65: one key into the second tile."""
     rows = frames * ntok
-    qkv = bf(rnd(rows, 1152, seed=1, scale=1.0))
+    qkv = rnd(rows, 1152, seed=1, scale=1.0)
     qkv[:, :384] *= 0.125 * 3 * 1.4426950408889634             # kernel contract: q carries log2(e)/8 (softmax on exp2)
-    out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
+    qkv = rd(qkv, dt)
+    out = torch.empty(rows, 384, dtype=DT[dt], device="cuda")
     qc = qkv.cuda()
-    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
+    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, dt, _st())
     q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.float().split(384, 1)]
     p = ((q @ k.transpose(-1, -2)) * 0.6931471805599453).softmax(-1)      # 2^(q.k) normalised
     want = (p @ v).transpose(1, 2).reshape(rows, 384)
-    np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), rtol=2e-2, atol=8e-3)
+    tol = (2e-2, 8e-3) if dt == 0 else (3e-3, 1e-3)              # P and O are rounded to the 16-bit format
+    np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), rtol=tol[0], atol=tol[1])
     att = torch.empty(frames, 6, ntok - 1, device="cuda")
-    _call("maavss_vit_cls_attn", qc.data_ptr(), att.data_ptr(), frames, ntok, 6, 1152, _st())
+    _call("maavss_vit_cls_attn", qc.data_ptr(), att.data_ptr(), frames, ntok, 6, 1152, dt, _st())
     np.testing.assert_allclose(att.cpu().numpy(), p[:, :, 0, 1:].numpy(), rtol=1e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("ntok,frames,ramp", [(1, 2, 0.0), (64, 2, 0.0), (129, 1, 0.0), (785, 1, 6.0), (300, 2, -6.0)])
-def test_vit_attention_edges_and_running_maximum(ntok, frames, ramp):
+@pytest.mark.parametrize("dt", [0, 2])
+@pytest.mark.parametrize("ntok,frames,ramp", [(1, 2, 0.0), (32, 2, 0.0), (33, 1, 0.0), (64, 2, 0.0), (129, 1, 0.0), (785, 1, 6.0), (300, 2, -6.0)])
+def test_vit_attention_edges_and_running_maximum(ntok, frames, ramp, dt):
     """Sequence lengths at the key-tile edges (1, exactly one tile, one key into the third tile) and score ramps along the
     keys: with ramp > 0 every key tile raises the row maximum far beyond the deferred-rescale threshold (the O / l rescale
     path runs tile after tile), with ramp < 0 the first tile holds the maximum and later tiles underflow to exact zeros."""
     rows = frames * ntok
-    qkv = bf(rnd(rows, 1152, seed=5, scale=1.0))
+    qkv = rnd(rows, 1152, seed=5, scale=1.0)
     qkv[:, :384] *= 0.125 * 3 * 1.4426950408889634
     if ramp:
         scale = torch.linspace(1.0, abs(ramp), ntok).repeat(frames)
         if ramp < 0:
             scale = scale.flip(0)
-        qkv[:, 384:768] = bf(qkv[:, 384:768].float() * scale[:, None])      # |k| grows (or shrinks) along the sequence
-    out = torch.empty(rows, 384, dtype=torch.bfloat16, device="cuda")
+        qkv[:, 384:768] = qkv[:, 384:768] * scale[:, None]      # |k| grows (or shrinks) along the sequence
+    qkv = rd(qkv, dt)
+    out = torch.empty(rows, 384, dtype=DT[dt], device="cuda")
     qc = qkv.cuda()
-    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, _st())
+    _call("maavss_vit_attn", qc.data_ptr(), out.data_ptr(), frames, ntok, 6, 1152, 384, dt, _st())
     q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.double().split(384, 1)]
     p = ((q @ k.transpose(-1, -2)) * 0.6931471805599453).softmax(-1)
     want = (p @ v).transpose(1, 2).reshape(rows, 384)
@@ -206,12 +228,13 @@ def test_attn_maps_temporal_diff():
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("act", ["bf16", "f16"])
 @pytest.mark.parametrize("width,frames", [(64, 4), (224, 2)])
-def test_video_attention_matches_oracle(width, frames):
+def test_video_attention_matches_oracle(width, frames, act):
     import maavss_amd
     from oracle import vit_ref_cpu as vref
     sd = vref.seeded_vit_state(3)
-    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth")
+    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act)
     va.load_state_dict(sd)
     fr = vref.synthetic_frames(frames, width, 5)
     with torch.no_grad():
@@ -220,12 +243,14 @@ def test_video_attention_matches_oracle(width, frames):
     got_cls = va.cls_attention(fr.cuda()).cpu()
     # bf16 activations through 12 blocks: compare the attention distributions, then the normalised maps
     err = (got_cls - want_cls).abs().max().item() / want_cls.abs().max().item()
-    assert err < 0.05, err
+    assert err < (0.05 if act == "bf16" else 0.01), err
     cos = F.cosine_similarity(got_cls.flatten(1), want_cls.flatten(1)).min().item()
-    assert cos > 0.999, cos
+    assert cos > (0.999 if act == "bf16" else 0.99995), cos
     got = va._inference(fr)
     assert got.shape == want.shape and got.device.type == "cpu"
-    # maps are in [0,1]; the ViT runs bf16 activations through 12 blocks (measured max deviation 0.047-0.053 with the
-    # deliberately sharpened random weights of the oracle recipe), the mean deviation is the tighter statement
-    assert (got - want).abs().max().item() < 0.08
-    assert (got - want).abs().mean().item() < 5e-3
+    # maps are in [0,1]; 16-bit activations through 12 blocks against the fp32 oracle.  bf16: measured max deviation
+    # 0.047-0.053 with the deliberately sharpened random weights of the oracle recipe; IEEE half (the default): 8x less
+    mx, mean = ((0.08, 5e-3) if act == "bf16" else (0.012, 7e-4))
+    print(f"[parity] ViT {act} {width}^2 vs fp32 oracle: max {(got - want).abs().max().item():.3e} mean {(got - want).abs().mean().item():.3e}")
+    assert (got - want).abs().max().item() < mx
+    assert (got - want).abs().mean().item() < mean
