@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--verbose", action="store_true", help="per-shape kernel table on stderr")
     ap.add_argument("--vit-chunk", type=int, default=0, help="frames per ViT launch group (0 = library default)")
     ap.add_argument("--sync-bn", action="store_true", help="global-batch BatchNorm statistics over the ranks (N > 1)")
+    ap.add_argument("--attn-dtype", choices=["same", "fp8"], default="same",
+                    help="fp8: Q K^T / P V of the ViT blocks on fp8 (e4m3) MFMA (BASELINE config 'fp8 MFMA attention'); the headline line uses 'same'")
+    ap.add_argument("--vit-dtype", choices=["f16", "bf16"], default="f16",
+                    help="16-bit storage / MFMA operand format of the ViT extractor (same MFMA rate; f16 meets the 1e-5 mask-MSE end to end)")
     return ap.parse_args()
 
 
@@ -161,7 +165,8 @@ def main():
     torch.manual_seed(1234)                  # replicas: identical initialisation on every rank (TrainStep also broadcasts rank 0's)
     frames, audio = synthetic_inputs(torch, b, t, w, length, 1234 + rank, dev)      # data: a different shard per rank
 
-    va = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth", device=dev)   # random init: no network
+    va = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth", device=dev, act_dtype=args.vit_dtype,
+                                   attn_dtype="fp8" if args.attn_dtype == "fp8" else None)   # random init: no network
     if args.vit_chunk:
         va.frames_per_launch = args.vit_chunk
     stft = maavss_amd.STFT(args.fft_len, hop, noise_std=0.1, device=dev)
@@ -223,6 +228,8 @@ def main():
                 return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
+            if name == "maavss_vit_attn_fp8":
+                return 4.0 * a[3] * a[5] * a[4] * a[4] * 64
             return 0.0
         def bytes_of(name, a):
             """Algorithmic HBM bytes of one launch: every operand read once, every result written once."""
@@ -235,6 +242,8 @@ def main():
                 return m * 384 * (4.0 if a[0] else 2.0) + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n
             if name == "maavss_vit_attn":
                 return a[2] * a[3] * (1152 + 384) * 2.0             # qkv in, attention output out, bf16
+            if name == "maavss_vit_attn_fp8":
+                return a[3] * a[4] * (1152 + 384) * 2.0
             return 0.0
         by_time = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
         dom_name, dom = by_time[0]
@@ -273,7 +282,7 @@ def main():
             if bytes_:
                 row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
             stages[name.replace("maavss_", "")] = row
-        for nm in ("maavss_vit_attn", "maavss_vit_panel_gemm", "maavss_vit_gemm"):
+        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_gemm"):
             if nm in summ:
                 stage_row(nm, sum(flops_of(nm, a) for a in summ[nm]["args"]), sum(bytes_of(nm, a) for a in summ[nm]["args"]))
         if "maavss_stft_fwd" in summ:      # audio in (4 B/sample) + y and x out (2 planes x T_a x F x 4 B each)
@@ -325,13 +334,13 @@ def main():
             "metric": metric, "value": round(clips / elapsed, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precise else "bf16", "data": "synthetic",
+            "dtype": "f32" if args.precise else args.vit_dtype, "data": "synthetic",
             "ms_per_step_without_kernel_events": round(elapsed_plain / args.steps * 1e3, 3),
             "config": {"workload": f"batch={b}/GPU, {t} frames {w}x{w}, {args.fft_len}-pt STFT, ViT-S/8 attention extraction "
-                                   f"(bf16 MFMA) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
+                                   f"({args.vit_dtype} MFMA operands, f32 accumulate) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
                        "parallelism": f"dp{world}", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
-                       "vit": "bf16", "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
+                       "vit": args.vit_dtype, "vit_attention": "fp8 e4m3" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
                        "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank",
                        "loss": loss_val},
             "roofline": roofline,

@@ -252,6 +252,13 @@ int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* l
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
                     void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream);
+/* fp8 (OCP e4m3) attention, BASELINE config "fp8 MFMA attention QK^T / AV" -- same call site (video_attention.py:52), same
+ * qkv / out tensors and layouts as maavss_vit_attn (`dtype` = their 16-bit format).  Per (frame, head) q, k and v are scaled
+ * by absmax / 448 and stored as e4m3 in `ws` (maavss_vit_attn_fp8_ws_bytes bytes, 16-byte aligned); Q K^T and P V run on
+ * v_mfma_f32_32x32x16_fp8_fp8 with f32 accumulation, the softmax in f32. */
+int64_t maavss_vit_attn_fp8_ws_bytes(int frames, int ntok, int heads);
+int maavss_vit_attn_fp8(const void* qkv, void* out, void* ws, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
+                        void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
                          int clip_frames, int attn_diff /* av_dataset.py:323-326, needs clip_frames > 0 */, void* stream);
 

@@ -99,7 +99,8 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
 
 class VideoAttention:
     def __init__(self, patch_size=8, threshold=0.6, path_to_weights="dino_deitsmall8_pretrain.pth",
-                 architecture="vit_small", resize=None, device="cuda", frames_per_launch=512, act_dtype="f16"):
+                 architecture="vit_small", resize=None, device="cuda", frames_per_launch=512, act_dtype="f16",
+                 attn_dtype=None):
         if patch_size != PATCH or architecture != "vit_small":
             raise ValueError("only DINO vit_small / patch 8 is built (the configuration the reference uses, "
                              "av_dataset.py:50)")
@@ -112,6 +113,11 @@ class VideoAttention:
             raise ValueError("act_dtype must be 'f16' or 'bf16'")
         self.act_dtype = act_dtype
         self.dt = DT_F16 if act_dtype == "f16" else DT_BF16
+        # attn_dtype="fp8": Q K^T and P V of the 11 full blocks on fp8 (e4m3) MFMA with per-(frame, head) scales
+        # (BASELINE config "fp8 MFMA attention"); None = the activation format.  The last block's CLS row stays 16-bit.
+        if attn_dtype not in (None, "fp8", act_dtype):
+            raise ValueError("attn_dtype must be None, 'fp8' or equal to act_dtype")
+        self.attn_fp8 = attn_dtype == "fp8"
         self.checkpoint_key = "teacher"
         self.device = torch.device(device)
         self.frames_per_launch = frames_per_launch
@@ -187,6 +193,9 @@ class VideoAttention:
         qkv = torch.empty(rpad, 3 * DIM, device=dev, dtype=tdt)
         att_o = torch.empty(rows, DIM, device=dev, dtype=tdt)
         hid = torch.empty(rpad, MLP, device=dev, dtype=tdt)
+        ws8 = None
+        if self.attn_fp8:
+            ws8 = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", f, ntok, HEADS), device=dev, dtype=torch.uint8)
         call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, dt, st)
         call("maavss_vit_gemm", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
              EPI_F32_ROWTABLE, 0, 1.0, dt, st)
@@ -206,7 +215,10 @@ class VideoAttention:
                      nqkv, DIM, EPI_BF16_BIAS, DIM, qs, dt, st)
             if i == DEPTH - 1:
                 break
-            call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
+            if self.attn_fp8:
+                call("maavss_vit_attn_fp8", ptr(qkv), ptr(att_o), ptr(ws8), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
+            else:
+                call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
             if self.fused_panel_gemm:
                 call("maavss_vit_panel_gemm", None, ptr(att_o), DIM, None, None, LN_EPS, ptr(b["proj_w"]), ptr(b["proj_b"]),
                      ptr(x), DIM, rpad, rows, DIM, EPI_F32_BIAS_RESID, 0, 1.0, dt, st)

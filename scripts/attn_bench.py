@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--zeros", action="store_true")
     a = ap.parse_args()
     rows = a.frames * a.ntok
-    tdt = {0: torch.bfloat16, 2: torch.float16}[a.dtype]
+    fp8 = a.dtype == 3            # fp8 attention on f16 qkv / out
+    tdt = {0: torch.bfloat16, 2: torch.float16, 3: torch.float16}[a.dtype]
     g = torch.Generator(device="cuda").manual_seed(1)
     qkv = torch.randn(rows, 1152, device="cuda", generator=g)
     qkv[:, :384] *= 0.125 * 1.4426950408889634
@@ -31,7 +32,11 @@ def main():
     qkv = qkv.to(tdt)
     out = torch.empty(rows, 384, device="cuda", dtype=tdt)
     st = _lib.stream_ptr()
-    run = lambda: _lib.call("maavss_vit_attn", qkv.data_ptr(), out.data_ptr(), a.frames, a.ntok, 6, 1152, 384, a.dtype, st)
+    if fp8:
+        ws = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", a.frames, a.ntok, 6), device="cuda", dtype=torch.uint8)
+        run = lambda: _lib.call("maavss_vit_attn_fp8", qkv.data_ptr(), out.data_ptr(), ws.data_ptr(), a.frames, a.ntok, 6, 1152, 384, 2, st)
+    else:
+        run = lambda: _lib.call("maavss_vit_attn", qkv.data_ptr(), out.data_ptr(), a.frames, a.ntok, 6, 1152, 384, a.dtype, st)
     for _ in range(5):
         run()
     torch.cuda.synchronize()

@@ -201,6 +201,31 @@ def test_adaptive_extension_224_matches_oracle(batch, frames):
         assert (p.grad.cpu() - gr).norm().item() <= 3e-3 * gr.norm().item() + 1e-7, k
 
 
+def test_config3_adaptive_384_32_frames_1024pt_matches_oracle():
+    """BASELINE config[3]: 32-frame 384^2 clips + 1024-pt STFT (F = 513, T_a = 256).  Like 224^2 this frame size is not
+    constructible in the reference (SURVEY finding 2): the 'adaptive' extension against the oracle twin, B = 1, exact-f32."""
+    from oracle import avse_ref_cpu as orc
+    m = dict(batch=1, frames=32, width=384, fft_len=1024, hops_per_frame=8, seed=29)
+    model, twin, (x_a, x_v, y_a, y_v) = _build(m, precise=True, spatial_match="adaptive")
+    assert model.s_v == 36 and model.n_bins == 513 and model.t_a == 256
+    orc.load_seeded(twin, m["seed"])
+    twin.train()
+    loss_ref, _, _, (a_ref, v_ref, f_ref) = orc.loss_ref(twin, x_a, x_v, y_a, y_v, 0.001, 1)
+    loss_ref.backward()
+    model.train()
+    a, v, fused = model(x_a.cuda(), x_v.cuda())
+    loss = torch.nn.functional.mse_loss(a, y_a.cuda()) + 0.001 * torch.nn.functional.mse_loss(v, y_v.cuda())
+    loss.backward()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), a_ref.detach().numpy(), rtol=0, atol=5e-5)
+    assert abs(loss.item() - loss_ref.item()) < 5e-6
+    ref_params = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        if k.startswith("stft_autoencoder.") or ref_params[k].grad is None:
+            continue
+        gr = ref_params[k].grad
+        assert (p.grad.cpu() - gr).norm().item() <= 5e-3 * gr.norm().item() + 1e-7, k
+
+
 def test_eval_mode_uses_running_statistics():
     """model.eval(): BatchNorm with running statistics, buffers untouched, matches the oracle twin in eval()."""
     from oracle import avse_ref_cpu as orc

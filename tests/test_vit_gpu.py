@@ -197,6 +197,63 @@ def test_vit_attention_edges_and_running_maximum(ntok, frames, ramp, dt):
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-2, atol=1.2e-2)
 
 
+def _fp8(x):
+    return x.to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("dt", [0, 2])
+@pytest.mark.parametrize("ntok,frames", [(785, 2), (97, 3), (2305, 1), (33, 2)])
+def test_vit_attention_fp8(ntok, frames, dt):
+    """fp8 (e4m3) attention, BASELINE config[4]: against torch fp32 on the SAME fp8-rounded, per-(frame, head)-scaled q / k / v
+    (so the tolerance covers the e4m3 rounding of the probabilities -- 3 mantissa bits, averaged over the keys -- and
+    accumulation order), and the distance to the unquantised attention reported next to it."""
+    rows = frames * ntok
+    qkv = rnd(rows, 1152, seed=11, scale=1.0)
+    qkv[:, :384] *= 0.125 * 3 * 1.4426950408889634
+    qkv = rd(qkv, dt)
+    out = torch.empty(rows, 384, dtype=DT[dt], device="cuda")
+    from maavss_amd import _lib
+    ws = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", frames, ntok, 6), dtype=torch.uint8, device="cuda")
+    qc = qkv.cuda()
+    _call("maavss_vit_attn_fp8", qc.data_ptr(), out.data_ptr(), ws.data_ptr(), frames, ntok, 6, 1152, 384, dt, _st())
+    q, k, v = [t.view(frames, ntok, 6, 64).transpose(1, 2) for t in qkv.float().split(384, 1)]      # [f, 6, n, 64]
+    exact = (((q @ k.transpose(-1, -2)) * 0.6931471805599453).softmax(-1) @ v).transpose(1, 2).reshape(rows, 384)
+    deq = []
+    for t in (q, k, v):
+        sc = t.abs().amax(dim=(2, 3), keepdim=True) / 448.0
+        deq.append(_fp8(t / sc) * sc)
+    q8, k8, v8 = deq
+    p = ((q8 @ k8.transpose(-1, -2)) * 0.6931471805599453).softmax(-1)
+    want = (p @ v8).transpose(1, 2).reshape(rows, 384)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    print(f"[fp8] ntok {ntok}: max|err| vs fp32 on fp8-rounded operands {err:.3e}; vs unquantised attention {(got - exact).abs().max().item():.3e} "
+          f"(|out| max {exact.abs().max().item():.2f})")
+    # P is rounded to e4m3 (relative step 2^-4 .. 2^-3): measured max 0.05-0.09 on outputs of magnitude <= 3.5, mean ~4e-3
+    assert err <= 0.12, err
+    assert (got - want).abs().mean().item() <= 1e-2
+
+
+def test_video_attention_fp8_attention_mode():
+    """VideoAttention(attn_dtype="fp8") end to end: map deviation vs the fp32 oracle, reported next to the 16-bit figure."""
+    import maavss_amd
+    from oracle import vit_ref_cpu as vref
+    sd = vref.seeded_vit_state(3)
+    fr = vref.synthetic_frames(2, 224, 5)
+    with torch.no_grad():
+        want = vref.inference_ref(sd, fr)
+    res = {}
+    for tag, kw in (("f16", {}), ("fp8", {"attn_dtype": "fp8"})):
+        va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", **kw)
+        va.load_state_dict(sd)
+        got = va._inference(fr)
+        res[tag] = ((got - want).abs().max().item(), (got - want).abs().mean().item())
+    print(f"[fp8] attention maps vs fp32 oracle: f16 max {res['f16'][0]:.3e} mean {res['f16'][1]:.3e}; "
+          f"fp8 attention max {res['fp8'][0]:.3e} mean {res['fp8'][1]:.3e}")
+    assert res["fp8"][0] < 0.25 and res["fp8"][1] < 2e-2
+
+
 def test_attn_maps_postprocess():
     from oracle import vit_ref_cpu as vref
     f, hp, wp = 6, 5, 4
@@ -228,9 +285,10 @@ def test_attn_maps_temporal_diff():
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("act", ["bf16", "f16"])
-@pytest.mark.parametrize("width,frames", [(64, 4), (224, 2)])
+@pytest.mark.parametrize("act,width,frames", [("bf16", 64, 4), ("f16", 64, 4), ("bf16", 224, 2), ("f16", 224, 2), ("f16", 384, 1)])
 def test_video_attention_matches_oracle(width, frames, act):
+    """384^2 = BASELINE config[3]: 2305 tokens per frame and the bicubic position-embedding interpolation of DINO
+    (the extractor's weights hold a 224^2 table)."""
     import maavss_amd
     from oracle import vit_ref_cpu as vref
     sd = vref.seeded_vit_state(3)
