@@ -82,10 +82,16 @@ struct Mma32<MODE_BF16> {
   static __device__ __forceinline__ void mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), acc, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x16 mma3(const bf16x8& a, const bf16x8& b, const f32x16& c) {   // D = A B + C, C kept
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+  }
 };
 template <>
 struct Mma32<MODE_F16> {
   static __device__ __forceinline__ void mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mma3(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), c, 0, 0, 0);
   }
 };

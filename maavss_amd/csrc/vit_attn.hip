@@ -7,7 +7,6 @@
 // runs on exp2); out is [rows][384] with heads concatenated.  Structure and layout notes sit above the kernel.
 // vit_cls_attn_kernel: last block only -- the CLS query against all keys, softmax over N tokens, the CLS
 // column dropped (video_attention.py:56): att [frames][6][N-1] f32.
-#include <stdlib.h>
 #include <type_traits>
 #include "mma.h"
 
@@ -65,6 +64,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
   float mrow = 0.f, lrow = 0.f;
+  f32x16 cinit;                          // -m_run in all 16 registers: the C operand of every tile's first MFMA
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cinit[e] = 0.f;
 
   uint4 kreg[2], vreg[2];
   const char* kframe = reinterpret_cast<const char*>(kbase + row0 * ld_qkv);
@@ -117,15 +119,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bf16_t* kt_base = &Ks[buf][0];
     const bf16_t* vt_base = &Vs[buf][0];
     __builtin_amdgcn_s_setprio(1);
+    // The running maximum enters as the first MFMA's C operand (s' = score - m_run, no subtraction pass) from a register
+    // block that only changes when m_run does: C and D of an MFMA may be different registers, so the 32 v_mov per tile that a
+    // re-initialised accumulator costs (15 % of the loop's vector issue) are not spent.
     f32x16 s[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[kb][e] = -mrow;
-#pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kt_base + kb * 32 * ATT_D + koff[ks]);
-        Mma32<MODE>::mma(s[kb], fk, fq[ks]);
+        if (ks == 0) s[kb] = Mma32<MODE>::mma3(fk, fq[0], cinit);
+        else Mma32<MODE>::mma(s[kb], fk, fq[ks]);
       }
     }
     if (decltype(last_c)::value && kv0 + NKB * 32 > ntok) {
@@ -164,6 +168,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const float delta = (first || mx > ATT_THR) ? mx : 0.f;
       const float alpha = fast_exp2(-delta);
       mrow += delta;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cinit[e] = -mrow;
       lrow *= alpha;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
