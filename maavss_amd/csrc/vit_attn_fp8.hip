@@ -93,14 +93,24 @@ __global__ __launch_bounds__(256) void vit_qkv_fp8_kernel(const bf16_t* __restri
         *reinterpret_cast<uint2*>(q8 + (row0 + r) * dim + head * F8_D + c8) = qo;
         *reinterpret_cast<uint2*>(k8 + (row0 + r) * dim + head * F8_D + c8) = ko;
       }
-      // V: key kl = 16 step + 8 a + 4 h + b goes to position 16 step + 8 h + 4 a + b of its 8 d rows (zeros past the end)
-      const int pos = (kl & ~15) | ((kl & 4) << 1) | ((kl & 8) >> 1) | (kl & 3);
+      // V: key kl = 16 step + 8 a + 4 h + b goes to position 16 step + 8 h + 4 a + b of its 8 d rows (zeros past the end):
+      // four consecutive keys (same a, h) are four consecutive positions = one dword per d row.  The four lanes that hold
+      // those keys for the same 8 d (lanes 8 apart) exchange their packed bytes and each writes the dwords of two d rows
+      // (dword instead of byte LDS stores; the kernel's 0.52 ms per launch is memory latency -- one workgroup walks a
+      // (frame, head)'s 785 rows twice with three loads in flight per thread -- not this exchange: DESIGN.md 9).
       const unsigned v01 = cvt_pk_fp8x4(f[2][0], f[2][1], f[2][2], f[2][3]), v23 = cvt_pk_fp8x4(f[2][4], f[2][5], f[2][6], f[2][7]);
+      const int jq = rsub & 3, lbase = lane - 8 * jq;
+      unsigned d01 = 0, d23 = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vt[c8 + e][pos] = (unsigned char)(v01 >> (8 * e));
-        vt[c8 + 4 + e][pos] = (unsigned char)(v23 >> (8 * e));
+      for (int i = 0; i < 4; ++i) {
+        const unsigned a01 = __shfl(v01, lbase + 8 * i, 64), a23 = __shfl(v23, lbase + 8 * i, 64);
+        d01 |= ((a01 >> (8 * jq)) & 0xffu) << (8 * i);
+        d23 |= ((a23 >> (8 * jq)) & 0xffu) << (8 * i);
       }
+      const int kl0 = kl & ~3;
+      const int pos0 = (kl0 & ~15) | ((kl0 & 4) << 1) | ((kl0 & 8) >> 1);
+      *reinterpret_cast<unsigned*>(&vt[c8 + jq][pos0]) = d01;
+      *reinterpret_cast<unsigned*>(&vt[c8 + 4 + jq][pos0]) = d23;
     }
     __syncthreads();
     {   // 64 d rows x 64 B: thread -> (d = tid >> 2, 16-B chunk tid & 3)
