@@ -14,6 +14,15 @@
 #define ATT_QT 128
 #define ATT_KT 64
 #define ATT_THR 5.0f  // log2 units: rescale only when the running maximum grows by more than 2^5
+// Ablation switches for measurement builds only (make ablate -> lib/libmaavss_ablate.so; results are WRONG by design):
+// bit 0 no exp, 1 no row sum, 2 no 16-bit pack, 3 no max chain, 4 no QK^T MFMAs, 5 no P V MFMAs, 6 no K/V staging after tile 0,
+// 7 no LDS fragment reads (fragments read once before the loop)
+#ifdef MAAVSS_ATTN_ABLATE
+#include <stdlib.h>
+#define ABL(bit) ((ABLM >> (bit)) & 1)
+#else
+#define ABL(bit) 0
+#endif
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -30,7 +39,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //            assignment come from two ds_read_b64_tr_b16 (64-B half of a V row ^= (key>>1)&1: every 32-lane half of a
 //            transposed read covers all 64 banks once).
 // The last key tile runs a single 32-key block when that covers the remaining keys (785 tokens: 17 of 64).
-template <int MODE>
+template <int MODE, int ABLM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void vit_attn_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ntok, int ld_qkv, int ld_out, int dim, int heads, int qblocks,
     int ngroups) {
@@ -68,6 +77,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int e = 0; e < 16; ++e) cinit[e] = 0.f;
 
+  // K / V staging through registers: the next tile's global loads (wave-uniform frame base + one 32-bit lane offset, clamped
+  // to the last row instead of predicated) are issued before the tile's MFMAs and written to LDS after them.  (LDS-DMA
+  // staging -- global_load_lds with the swizzles applied on the source side -- was measured 4-8 % SLOWER)
   uint4 kreg[2], vreg[2];
   const char* kframe = reinterpret_cast<const char*>(kbase + row0 * ld_qkv);
   const char* vframe = reinterpret_cast<const char*>(vbase + row0 * ld_qkv);
@@ -103,9 +115,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   const int ntiles = (ntok + ATT_KT - 1) / ATT_KT;
   const bool last_half = ntok - (ntiles - 1) * ATT_KT <= 32;   // the last tile's keys fit one 32-key block
-  load_tile();
-  store_tile(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // volatile: keeps the chain behind the wait-state asm above (volatile asm statements are not reordered among themselves)
   auto max3 = [](float a, float b, float c) __attribute__((always_inline)) {
@@ -127,8 +138,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(kt_base + kb * 32 * ATT_D + koff[ks]);
-        if (ks == 0) s[kb] = Mma32<MODE>::mma3(fk, fq[0], cinit);
+        bf16x8 fk;
+        if (ABL(7)) fk = fq[ks]; else fk = *reinterpret_cast<const bf16x8*>(kt_base + kb * 32 * ATT_D + koff[ks]);
+        if (ABL(4)) { if (ks == 0) s[kb] = cinit; asm volatile("" : "+v"(s[kb]), "+v"(fk)); }
+        else if (ks == 0) s[kb] = Mma32<MODE>::mma3(fk, fq[0], cinit);
         else Mma32<MODE>::mma(s[kb], fk, fq[ks]);
       }
     }
@@ -148,7 +161,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if constexpr (NKB == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
     else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0]));
     float mx;
-    {
+    if (ABL(3)) mx = s[0][0];
+    else {
       float a[NKB][5];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -187,15 +201,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float p = fast_exp2(s[kb][e]);
+          const float p = ABL(0) ? s[kb][e] : fast_exp2(s[kb][e]);
           s[kb][e] = p;
-          sum += p;
+          if (!ABL(1) || e == 0) sum += p;
         }
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
           const uint4 u = make_uint4(pack2<MODE>(s[kb][8 * sx], s[kb][8 * sx + 1]), pack2<MODE>(s[kb][8 * sx + 2], s[kb][8 * sx + 3]),
                                      pack2<MODE>(s[kb][8 * sx + 4], s[kb][8 * sx + 5]), pack2<MODE>(s[kb][8 * sx + 6], s[kb][8 * sx + 7]));
-          fp[kb][sx] = __builtin_bit_cast(bf16x8, u);
+          if (ABL(2)) { const uint4 u2 = make_uint4(__float_as_uint(s[kb][8 * sx]), __float_as_uint(s[kb][8 * sx + 2]), __float_as_uint(s[kb][8 * sx + 4]), __float_as_uint(s[kb][8 * sx + 6])); fp[kb][sx] = __builtin_bit_cast(bf16x8, u2); }
+          else fp[kb][sx] = __builtin_bit_cast(bf16x8, u);
         }
       }
       lrow += sum;
@@ -209,22 +224,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16_t* a0 = vt_base + (kb * 32 + sx * 16) * ATT_D + voff[db];
-          const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
-          const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * ATT_D));
-          Mma32<MODE>::mma(o[db], concat4(h0, h1), fp[kb][sx]);
+          bf16x8 fv;
+          if (ABL(7)) fv = fq[sx + 2 * db];
+          else {
+            const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+            const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * ATT_D));
+            fv = concat4(h0, h1);
+          }
+          if (ABL(5)) asm volatile("" : "+v"(o[db]) : "v"(fv), "v"(fp[kb][sx]));
+          else Mma32<MODE>::mma(o[db], fv, fp[kb][sx]);
         }
     __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < ntiles - 1; ++kt) {
-    load_tile();
-    __builtin_amdgcn_sched_barrier(0);
+    if (!ABL(6)) load_tile();
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here: their latency is covered by the tile's MFMAs
     if (wave_active) tile(kt, std::false_type{}, std::integral_constant<int, 2>{});
+    // the LDS writes stay below the tile's MFMAs (hipcc otherwise merges them into the load block above)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       asm volatile("" : "+v"(kreg[it].x), "+v"(kreg[it].y), "+v"(kreg[it].z), "+v"(kreg[it].w));
       asm volatile("" : "+v"(vreg[it].x), "+v"(vreg[it].y), "+v"(vreg[it].z), "+v"(vreg[it].w));
     }
-    store_tile((kt & 1) ^ 1);
+    if (!ABL(6)) store_tile((kt & 1) ^ 1);
     __syncthreads();
   }
   if (wave_active) {
@@ -310,6 +332,18 @@ extern "C" int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok,
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
   hipStream_t st = (hipStream_t)stream;
+#ifdef MAAVSS_ATTN_ABLATE
+  {
+    const char* e = getenv("MAAVSS_ATTN_ABL");
+    const int m = e ? atoi(e) : 0;
+#define ABL_CASE(M) case M: hipLaunchKernelGGL((vit_attn_kernel<MODE_F16, M>), dim3(nblocks), dim3(256), 0, st, q, o, ntok, ld_qkv, ld_out, heads * ATT_D, heads, qblocks, ngroups); break;
+    switch (m) { ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(7) ABL_CASE(8) ABL_CASE(15) ABL_CASE(16) ABL_CASE(32) ABL_CASE(48) ABL_CASE(64) ABL_CASE(128) ABL_CASE(192) ABL_CASE(207) ABL_CASE(240)
+      default: MAAVSS_CHECK_ARG(false, "vit_attn (ablation build): mask %d not instantiated", m); }
+#undef ABL_CASE
+    MAAVSS_LAUNCH_CHECK("vit_attn_kernel");
+    return MAAVSS_OK;
+  }
+#endif
   if (dtype == MODE_F16)
     hipLaunchKernelGGL(vit_attn_kernel<MODE_F16>, dim3(nblocks), dim3(256), 0, st, q, o, ntok, ld_qkv, ld_out, heads * ATT_D, heads, qblocks, ngroups);
   else

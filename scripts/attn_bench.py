@@ -12,6 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maavss_amd import _lib  # noqa: E402
 
+if os.environ.get("MAAVSS_LIB"):          # measurement builds (make -C maavss_amd/csrc ablate)
+    _lib.LIB_PATH = os.environ["MAAVSS_LIB"]
+
 
 def main():
     ap = argparse.ArgumentParser()
