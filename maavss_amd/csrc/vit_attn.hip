@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   const int ntiles = (ntok + ATT_KT - 1) / ATT_KT;
   const bool last_half = ntok - (ntiles - 1) * ATT_KT <= 32;   // the last tile's keys fit one 32-key block
-  dma_tile(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  load_tile();
+  store_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the Q fragments too, so that no wait on them lands inside the loop
   __syncthreads();
   // volatile: keeps the chain behind the wait-state asm above (volatile asm statements are not reordered among themselves)
   auto max3 = [](float a, float b, float c) __attribute__((always_inline)) {
