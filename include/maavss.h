@@ -67,14 +67,17 @@ int maavss_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int
  * or f32 (precise=1): mode 0 = forward (n=Co), mode 1 = input gradient (n=Ci; flipped taps, use pad 4-p).
  * igemm: y[B][T][Ho][Wo][c_out], Ho = H+2*pad-4; stat_partials (nullable) [grid blocks][2][c_out] receives
  * per-block (sum, sum^2) for BatchNorm, grid blocks = ceil(Wo/16)*ceil(Ho/16)*B*T.
- * wgrad: dw[Co][Ci][3][5][5] (+= when beta=1); ws of maavss_conv3d_wgrad_ws_bytes(c_in,c_out,nchunk) bytes. */
+ * wgrad: dw[Co][Ci][3][5][5] (+= when beta=1); ws of maavss_conv3d_wgrad_ws_bytes(c_in,c_out,nchunk) bytes.
+ * x16 / dy16 = 1: that operand is already stored in the MFMA format of `precise` (IEEE half x from
+ * maavss_bn_pool_act_fwd's out16 for the forward pass, bf16 dy from maavss_bn_pool_act_bwd for the two backward passes):
+ * the producer rounded once, the kernels copy instead of converting -- bit-identical results, half the bytes. */
 int maavss_conv3d_kp(int c_in);
 int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, int c_in, int mode, int precise, void* stream);
-int maavss_conv3d_igemm(const float* x, const void* wt, float* y, float* stat_partials, int B, int T, int H, int W,
-                        int c_in, int c_out, int pad, int precise, void* stream);
+int maavss_conv3d_igemm(const void* x, const void* wt, float* y, float* stat_partials, int B, int T, int H, int W,
+                        int c_in, int c_out, int pad, int precise, int x16, void* stream);
 int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk);
-int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
-                        int c_in, int c_out, int pad, int beta, int precise, void* stream);
+int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
+                        int c_in, int c_out, int pad, int beta, int precise, int dy16, void* stream);
 /* first layer (C_in = 1, pad 2): x [B][T][H][W], w [16][1][3][5][5], w16_ws 1200 floats scratch,
  * y [B][T][H][W][16]; stat_partials as above; wgrad ws = nchunk*1200 floats. */
 int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B, int T,
@@ -106,14 +109,19 @@ int maavss_bn_eval_stats(const float* running_mean, const float* running_var, fl
                          void* stream);
 int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C, int pool,
-                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
+                           void* out16 /* nullable: IEEE-half copy of the pooled activation, contiguous channels-last
+                                          [B][T][Hp][Wp][C] -- the operand format of the next Conv3d's forward MFMA */,
+                           void* stream);
 /* beta (nullable): with it, LeakyReLU layers recover the normalised input at the pooled maximum from `out` instead of
  * gathering it from y (xhat = (leaky^-1(out) - beta) / gamma; channels with |gamma| < 1e-2 still gather).  dy NULL: only
  * dgamma / dbeta and the coefficients (see maavss_conv3d_c1_wgrad_bn). */
 int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
-                           const float* mean, const float* invstd, const float* gamma, const float* beta, float* dy, float* dgamma,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, void* dy, float* dgamma,
                            float* dbeta, int accumulate, float* ws, int B, int T, int H, int W, int C, int pool,
-                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+                           int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
+                           int dy_bf16 /* 1: dy is written as bf16 (what both of its MFMA consumers round it to), 0: f32 */,
+                           void* stream);
 
 /* Global-batch BatchNorm under data parallelism (the reference normalises over the WHOLE batch on one device,
  * avse_model_final.py:35,40,45,50,55,103): split forms whose per-channel sums -- double sums[2*C + 1] = {sum, sum^2 (or
@@ -129,10 +137,10 @@ int maavss_bn_pool_act_bwd_sums(const float* dout, const float* out, const void*
                                 int T, int H, int W, int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p,
                                 int64_t os_c, void* stream);
 int maavss_bn_pool_act_bwd_finish(const float* dout, const float* out, const void* argmax, const float* y, const float* mean,
-                                  const float* invstd, const float* gamma, const float* beta, float* dy, float* dgamma,
+                                  const float* invstd, const float* gamma, const float* beta, void* dy, float* dgamma,
                                   float* dbeta, int accumulate, const double* sums_local, const double* sums_global,
                                   float* coef, int B, int T, int H, int W, int C, int pool, int act, int64_t os_b,
-                                  int64_t os_t, int64_t os_p, int64_t os_c, void* stream);
+                                  int64_t os_t, int64_t os_p, int64_t os_c, int dy_bf16, void* stream);
 
 /* ---- K10 Conv2d(k=(3,9), stride (sh,sw), pad (1,pw), bias=False) -- avse_model_final.py:98-102 ----
  * in_layout 0: x NCHW [B][Ci][H][W] (network input), 1: NHWC; y/dy NHWC [B][Ho][Wo][Co]; w [Co][Ci][3][9].

@@ -473,8 +473,11 @@ class AV_Fusion_Model_Frames(nn.Module):
         ts = t * self.s_v
         seq = torch.empty(b, self.latent_channels, 2 * ts, device=dev, dtype=torch.float32)
         sv = {"x_v": x_v, "x_a": x_a, "seq": seq, "vis": [], "aud": []}
-        # --- visual encoder (K7-K9)
+        # --- visual encoder (K7-K9).  16-bit path: every pooled activation is also written as IEEE half by its producer
+        # (the rounding the next conv's MFMA staging would apply, done once), so that conv reads half the bytes and copies;
+        # the f32 tensor stays for the backward pass (weight gradient operand, BatchNorm / LeakyReLU backward).
         act_in = x_v.view(b, t, w, w)
+        act_in16 = None
         for i in range(5):
             conv, bn = self._vis(i)
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
@@ -482,14 +485,19 @@ class AV_Fusion_Model_Frames(nn.Module):
                 y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=train)
             else:
                 wt = ops.conv3d_prep(conv.weight.detach(), 0, pr)
-                y, part = ops.conv3d_igemm(act_in, wt, co, pad, pr, want_stats=train)
+                y, part = ops.conv3d_igemm(act_in if act_in16 is None else act_in16, wt, co, pad, pr, want_stats=train)
             hh, ww = y.shape[2], y.shape[3]
             if train:
                 mean, invstd = self._bn_train_stats(part, b * t * hh * ww, bn)
             else:
                 mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
+            act_in16 = None
             if i < 4:
-                out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
+                if self.precise:
+                    out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
+                else:
+                    out, arg, act_in16 = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
+                                                             ops.BN_LEAKY, want16=True)
                 strides = None
             else:   # write the [B,16,T,S] block of the LSTM sequence directly (avse_model_final.py:58,239-240)
                 strides = (self.latent_channels * 2 * ts, self.s_v, 1, 2 * ts)
@@ -651,9 +659,10 @@ class AV_Fusion_Model_Frames(nn.Module):
                                            dw=buf, beta=beta)
                     out_grads[wname] = buf
                 continue
+            # 16-bit path: dy is written as bf16 -- what both of its consumers (weight gradient, input gradient) round it to
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
                                      ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(),
-                                     reduce_fn=self._bn_sync)
+                                     reduce_fn=self._bn_sync, dy_bf16=not self.precise)
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __res
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, unsigned char* __restrict__ argmax,
-                                                              PoolGeom g, int act) {
+                                                              unsigned short* __restrict__ out16, PoolGeom g, int act) {
   const int C4 = g.C >> 2;
   const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -141,12 +141,16 @@ __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __res
       }
     const int b = bt / g.T, t = bt % g.T;
     float* op = out + b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+    const float a4[4] = {act_fwd(best[0], act), act_fwd(best[1], act), act_fwd(best[2], act), act_fwd(best[3], act)};
     if (g.osC == 1) {
-      *reinterpret_cast<float4*>(op) = make_float4(act_fwd(best[0], act), act_fwd(best[1], act), act_fwd(best[2], act), act_fwd(best[3], act));
+      *reinterpret_cast<float4*>(op) = make_float4(a4[0], a4[1], a4[2], a4[3]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) op[e * g.osC] = act_fwd(best[e], act);
+      for (int e = 0; e < 4; ++e) op[e * g.osC] = a4[e];
     }
+    // the next Conv3d's forward MFMA rounds this activation to IEEE half when it stages it: done here once instead
+    // (same rounding, same value), so that its halo becomes a plain copy of half the bytes
+    if (out16 != nullptr) *reinterpret_cast<uint2*>(out16 + pos * g.C + c) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
     if (argmax != nullptr) *reinterpret_cast<uchar4*>(argmax + pos * g.C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
   }
 }
@@ -240,10 +244,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   coef[2 * C + c] = (float)(s2 / count);
 }
 
+template <bool DY16>
 __global__ __launch_bounds__(256) void bn_pool_act_bwd_dx_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
     const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ coef, float* __restrict__ dy, PoolGeom g, int act) {
+    const float* __restrict__ coef, void* __restrict__ dy_, PoolGeom g, int act) {
   const int C = g.C, C4 = C >> 2;
   const int64_t total = (int64_t)g.BT * g.H * g.W * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -278,7 +283,10 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_dx_kernel(
     o.y = k0.y * (gg[1] - k1.y - (yv.y - mu.y) * is.y * k2.y);
     o.z = k0.z * (gg[2] - k1.z - (yv.z - mu.z) * is.z * k2.z);
     o.w = k0.w * (gg[3] - k1.w - (yv.w - mu.w) * is.w * k2.w);
-    *reinterpret_cast<float4*>(dy + pos * C + c) = o;
+    // DY16: both consumers of dy (the input-gradient and the weight-gradient MFMA kernels) round it to bf16 when they stage
+    // it -- rounded here once instead (bit-identical operands), written and re-read at half the bytes
+    if constexpr (DY16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dy_) + pos * C + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dy_) + pos * C + c) = o;
   }
 }
 
@@ -353,24 +361,33 @@ extern "C" int maavss_bn_eval_stats(const float* running_mean, const float* runn
 extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                                       const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C,
                                       int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
-                                      void* stream) {
+                                      void* out16, void* stream) {
   MAAVSS_CHECK_ARG(y && mean && invstd && gamma && beta && out, "bn_pool_act_fwd: null pointer");
   if (int rc = check_geom("bn_pool_act_fwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_fwd: argmax buffer required when pool > 1");
   PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
   const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * (C / 4);
   hipLaunchKernelGGL(bn_pool_act_fwd_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, g, act);
+                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, (unsigned short*)out16, g, act);
   MAAVSS_LAUNCH_CHECK("bn_pool_act_fwd_kernel");
   return MAAVSS_OK;
 }
 
 // ws: at least (2*C*nblk + 3*C) floats with nblk = maavss_bn_stats_nblk(B*T*Hp*Wp); coef = ws + 2*C*nblk
+#define BN_DX_LAUNCH()                                                                                                        \
+  {                                                                                                                           \
+    const int64_t total = (int64_t)g.BT * H * W * (C / 4);                                                                    \
+    const dim3 grid(min((int64_t)8192, (total + 255) / 256));                                                                 \
+    if (dy_bf16) hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel<true>, grid, dim3(256), 0, st, dout, out, (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act); \
+    else hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel<false>, grid, dim3(256), 0, st, dout, out, (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);       \
+    MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");                                                                         \
+  }
+
 extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const void* argmax, const float* y,
-                                      const float* mean, const float* invstd, const float* gamma, const float* beta, float* dy,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta, void* dy,
                                       float* dgamma, float* dbeta, int accumulate, float* ws, int B, int T, int H, int W,
                                       int C, int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
-                                      void* stream) {
+                                      int dy_bf16, void* stream) {
   MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && ws, "bn_pool_act_bwd: null pointer");
   if (int rc = check_geom("bn_pool_act_bwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_bwd: argmax buffer required when pool > 1");
@@ -388,10 +405,7 @@ extern "C" int maavss_bn_pool_act_bwd(const float* dout, const float* out, const
                      accumulate, coef, inverse ? beta : nullptr);
   MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_kernel");
   if (dy == nullptr) return MAAVSS_OK;   // the consumer applies the coefficients itself (maavss_conv3d_c1_wgrad_bn)
-  const int64_t total = (int64_t)g.BT * H * W * (C / 4);
-  hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
-                     (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);
-  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");
+  BN_DX_LAUNCH()
   return MAAVSS_OK;
 }
 
@@ -500,9 +514,9 @@ extern "C" int maavss_bn_pool_act_bwd_sums(const float* dout, const float* out, 
 
 extern "C" int maavss_bn_pool_act_bwd_finish(const float* dout, const float* out, const void* argmax, const float* y,
                                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                             float* dy, float* dgamma, float* dbeta, int accumulate, const double* sums_local,
+                                             void* dy, float* dgamma, float* dbeta, int accumulate, const double* sums_local,
                                              const double* sums_global, float* coef, int B, int T, int H, int W, int C, int pool,
-                                             int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, void* stream) {
+                                             int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c, int dy_bf16, void* stream) {
   MAAVSS_CHECK_ARG(dout && out && y && mean && invstd && gamma && sums_local && sums_global && coef,
                    "bn_pool_act_bwd_finish: null pointer");
   if (int rc = check_geom("bn_pool_act_bwd_finish", B, T, H, W, C, pool)) return rc;
@@ -513,9 +527,6 @@ extern "C" int maavss_bn_pool_act_bwd_finish(const float* dout, const float* out
                      dbeta, accumulate, coef, inverse ? beta : nullptr);
   MAAVSS_LAUNCH_CHECK("bn_bwd_finalize_sums_kernel");
   if (dy == nullptr) return MAAVSS_OK;
-  const int64_t total = (int64_t)g.BT * H * W * (C / 4);
-  hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0, st, dout, out,
-                     (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);
-  MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");
+  BN_DX_LAUNCH()
   return MAAVSS_OK;
 }

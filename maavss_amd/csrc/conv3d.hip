@@ -69,12 +69,19 @@ __device__ __forceinline__ TileId xcd_tile(int nx, int ny, int64_t total) {
 }
 static inline int xcd_grid(int64_t total) { return (int)(((total + 7) / 8) * 8); }
 
-template <int PRECISE, int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restrict__ x,
+// IN16: x is already stored in the MFMA operand format (IEEE half for the forward pass, bf16 for the input-gradient pass:
+// the producers bn_pool_act_fwd / bn_pool_act_bwd round once instead of every consumer) -- the halo is then a plain copy of
+// half the bytes: by LDS-DMA for C_in = 16 / 32 (no staging registers: these variants are VGPR-limited and ran a
+// load -> convert -> store loop with ONE load in flight per thread, a third of their time), by the register prefetch for 64.
+template <int PRECISE, int CIN, int COUT, bool IN16 = false>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restrict__ x_,
                                                            const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                            float* __restrict__ y, float* __restrict__ stat_partials,
                                                            int n_bt, int T, int H, int W, int Ho, int Wo, int pad, int KP) {
   using M = Mma<PRECISE>;
+  static_assert(!IN16 || PRECISE != MODE_F32, "16-bit input needs a 16-bit MFMA mode");
+  const float* x = reinterpret_cast<const float*>(x_);
+  const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x_);
   using E = typename M::elem;
   constexpr int ES = sizeof(E), EPC = 16 / ES;       // elements per 16-byte chunk
   constexpr int RBH = CIN * ES, NCH = RBH / 16;       // halo: bytes / chunks per position
@@ -104,21 +111,26 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
   // workgroups per CU (60 - 70 KB of LDS each), too few to cover that; the same LDS limit leaves 256 VGPRs per lane,
   // so the 100 staging registers are free.  (Scratch build without the halo loads: igemm 4.3 -> 2.9 ms per step.)
   // The smaller C_in variants run 3 - 5 workgroups per CU and keep the plain loop (batched loads cost them occupancy).
-  constexpr int HV = 400 * (CIN / 4), NV = (HV + 255) / 256;
+  constexpr int VE = IN16 ? 8 : 4;                      // elements per 16-byte global vector
+  constexpr int HV = 400 * (CIN / VE), NV = (HV + 255) / 256;
   constexpr bool PREFETCH = CIN >= 64;
-  float4 hv[PREFETCH ? NV : 1];
+  float4 hv[PREFETCH ? NV : 1];                         // IN16: the same 16 bytes hold 8 operand elements
   auto fetch = [&](int kd) __attribute__((always_inline)) {
-    const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
+    const int64_t plane = (int64_t)(bt + kd - 1) * H * W * CIN;
     int tv = tid;
     asm volatile("" : "+v"(tv));   // the index arithmetic is redone per call: hoisted out of the kd loop it costs 100+ registers
 #pragma unroll
     for (int j = 0; j < (PREFETCH ? NV : 1); ++j) {
       const int i = tv + j * 256;
-      const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+      const int pos = i / (CIN / VE), cv = (i % (CIN / VE)) * VE;
       const int r = pos / 20, c = pos % 20;
       const int iy = y0 + r - pad, ix = x0 + c - pad;
       hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < HV && iy >= 0 && iy < H && ix >= 0 && ix < W) hv[j] = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
+      if (i < HV && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const int64_t e = plane + ((int64_t)iy * W + ix) * CIN + cv;
+        if constexpr (IN16) hv[j] = *reinterpret_cast<const float4*>(x16 + e);
+        else hv[j] = *reinterpret_cast<const float4*>(x + e);
+      }
     }
   };
   auto stash = [&]() __attribute__((always_inline)) {
@@ -128,9 +140,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
     for (int j = 0; j < (PREFETCH ? NV : 1); ++j) {
       const int i = tv + j * 256;
       if (i < HV) {
-        const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4, c = pos % 20;
-        E* d = halo + (pos * NCH + swz<RBH>(c, c4 / EPC)) * EPC + (c4 % EPC);
-        d[0] = M::cvt(hv[j].x); d[1] = M::cvt(hv[j].y); d[2] = M::cvt(hv[j].z); d[3] = M::cvt(hv[j].w);
+        const int pos = i / (CIN / VE), cv = (i % (CIN / VE)) * VE, c = pos % 20;
+        E* d = halo + (pos * NCH + swz<RBH>(c, cv / EPC)) * EPC + (cv % EPC);
+        if constexpr (IN16) {
+          *reinterpret_cast<float4*>(d) = hv[j];
+        } else {
+          d[0] = M::cvt(hv[j].x); d[1] = M::cvt(hv[j].y); d[2] = M::cvt(hv[j].z); d[3] = M::cvt(hv[j].w);
+        }
       }
     }
   };
@@ -141,6 +157,26 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
     // ---- stage the 20x20xCIN halo of frame t + kd - 1 (zero-filled outside the image)
     if constexpr (PREFETCH) {
       stash();
+    } else if constexpr (IN16) {
+      // LDS-DMA: 16 B per lane straight into the halo image.  The DMA writes lane-linearly (slot i = position i / NCH, physical
+      // chunk i % NCH), so the swizzle is applied on the SOURCE side (XOR: its own inverse).  Positions outside the image read
+      // the zero padding at the end of weight row 0 (k >= 25 C_in; 96 / 64 bytes for C_in = 16 / 32) -- no predication, the
+      // wave stays whole, the destination base stays lane 0's.
+      static_assert(CIN == 16 || CIN == 32, "the zero source relies on the padded tail of the weight rows");
+      const unsigned short* xp = x16 + (int64_t)(bt + kd - 1) * H * W * CIN;
+      const unsigned short* zeros = reinterpret_cast<const unsigned short*>(wt) + 25 * CIN;
+      for (int i0 = 0; i0 < HV; i0 += 256) {
+        const int i = i0 + tid;
+        if (i < HV) {
+          const int pos = i / NCH, pc = i % NCH;
+          const int r = pos / 20, c = pos % 20;
+          const int iy = y0 + r - pad, ix = x0 + c - pad;
+          const unsigned short* src = zeros;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) src = xp + ((int64_t)iy * W + ix) * CIN + swz<RBH>(c, pc) * EPC;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(halo + (int64_t)i * EPC), 16, 0, 0);
+        }
+      }
     } else {
       const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
       for (int i = tid; i < HV; i += 256) {
@@ -160,6 +196,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
       *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) =
           *reinterpret_cast<const uint4*>(wk + (int64_t)n * KP + c * EPC);
     }
+    if constexpr (IN16 && !PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo DMA has landed
     __syncthreads();
     if constexpr (PREFETCH) {
       if (kd < kd_hi) fetch(kd + 1);
@@ -268,12 +305,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float* __restri
   }
 }
 
-template <int PRECISE, int CIN, int COUT>
-static int launch_igemm(const float* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
+template <int PRECISE, int CIN, int COUT, bool IN16 = false>
+static int launch_igemm(const void* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
                         int Wo, int pad, int KP, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
   const size_t smem = (400 * CIN + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
-  auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT>;
+  auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT, IN16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
   hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP);
@@ -296,9 +333,10 @@ extern "C" int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, i
   return MAAVSS_OK;
 }
 
-extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, float* stat_partials, int B, int T, int H,
-                                   int W, int c_in, int c_out, int pad, int precise, void* stream) {
+extern "C" int maavss_conv3d_igemm(const void* x, const void* wt, float* y, float* stat_partials, int B, int T, int H,
+                                   int W, int c_in, int c_out, int pad, int precise, int x16, void* stream) {
   MAAVSS_CHECK_ARG(x && wt && y, "conv3d_igemm: null pointer");
+  MAAVSS_CHECK_ARG(!x16 || precise != MODE_F32, "conv3d_igemm: 16-bit input needs precise = 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(pad >= 0 && pad <= 4, "conv3d_igemm: pad must be in [0,4]");
   MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_igemm: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
@@ -308,7 +346,9 @@ extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, flo
 #define CASE(CI, CO)                                                                                          \
   if (c_in == CI && c_out == CO) {                                                                            \
     if (precise == MODE_F32) launch_igemm<MODE_F32, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);      \
+    else if (precise == MODE_F16 && x16) launch_igemm<MODE_F16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
     else if (precise == MODE_F16) launch_igemm<MODE_F16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else if (x16) launch_igemm<MODE_BF16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
     else launch_igemm<MODE_BF16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_igemm_kernel");                                                               \
     return MAAVSS_OK;                                                                                         \
@@ -321,8 +361,9 @@ extern "C" int maavss_conv3d_igemm(const float* x, const void* wt, float* y, flo
 
 // --------------------------------------------------------------------------------------------
 // weight gradient
-template <int PRECISE, int CI, int CO>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// DY16: dy arrives already rounded to the MFMA operand format (bn_pool_act_bwd writes it as bf16): copied, not converted
+template <int PRECISE, int CI, int CO, bool DY16 = false>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dy_,
                                                            float* __restrict__ partials, int BT, int T, int H, int W,
                                                            int Ho, int Wo, int pad, int tiles_x, int tiles_y,
                                                            int tiles_per_chunk, int nchunk) {
@@ -366,14 +407,26 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
       E* d = xs + pos * CI + c4;
       d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
     }
-    const float* dp = dy + (int64_t)bt * Ho * Wo * CO;
-    for (int i = tid; i < 256 * (CO / 4); i += 256) {
-      const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
-      const int oy = y0 + pos / 16, ox = x0 + pos % 16;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
-      E* d = ds + pos * CO + c4;
-      d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+    if constexpr (DY16) {
+      static_assert(PRECISE != MODE_F32, "16-bit dy needs a 16-bit MFMA mode");
+      const unsigned short* dp = reinterpret_cast<const unsigned short*>(dy_) + (int64_t)bt * Ho * Wo * CO;
+      for (int i = tid; i < 256 * (CO / 8); i += 256) {
+        const int pos = i / (CO / 8), c8 = (i % (CO / 8)) * 8;
+        const int oy = y0 + pos / 16, ox = x0 + pos % 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (oy < Ho && ox < Wo) v = *reinterpret_cast<const uint4*>(dp + ((int64_t)oy * Wo + ox) * CO + c8);
+        *reinterpret_cast<uint4*>(ds + pos * CO + c8) = v;
+      }
+    } else {
+      const float* dp = reinterpret_cast<const float*>(dy_) + (int64_t)bt * Ho * Wo * CO;
+      for (int i = tid; i < 256 * (CO / 4); i += 256) {
+        const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
+        const int oy = y0 + pos / 16, ox = x0 + pos % 16;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
+        E* d = ds + pos * CO + c4;
+        d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      }
     }
     __syncthreads();
 #pragma unroll 2
@@ -477,19 +530,19 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
   }
 }
 
-int maavss_conv3d_wgrad_wide_try(const float* x, const float* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
-                                 int Wo, int c_in, int c_out, int pad, int mode, hipStream_t st);  // conv3d_wgrad_wide.hip
+int maavss_conv3d_wgrad_wide_try(const float* x, const void* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
+                                 int Wo, int c_in, int c_out, int pad, int mode, int dy16, hipStream_t st);  // conv3d_wgrad_wide.hip
 
 extern "C" int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk) {
   return (int64_t)nchunk * 75 * c_in * c_out * 4;
 }
 
-template <int PRECISE, int CI, int CO>
-static void launch_wgrad(const float* x, const float* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
+template <int PRECISE, int CI, int CO, bool DY16 = false>
+static void launch_wgrad(const float* x, const void* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                          int nchunk, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
   const size_t smem = (320 * CI + 256 * CO) * sizeof(E);
-  auto kern = conv3d_wgrad_kernel<PRECISE, CI, CO>;
+  auto kern = conv3d_wgrad_kernel<PRECISE, CI, CO, DY16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
   const int tiles_total = BT * tiles_x * tiles_y;
@@ -498,16 +551,17 @@ static void launch_wgrad(const float* x, const float* dy, float* ws, int BT, int
                      tiles_y, tpc, nchunk);
 }
 
-extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
-                                   int W, int c_in, int c_out, int pad, int beta, int precise, void* stream) {
+extern "C" int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
+                                   int W, int c_in, int c_out, int pad, int beta, int precise, int dy16, void* stream) {
   MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_wgrad: null pointer");
+  MAAVSS_CHECK_ARG(!dy16 || precise == MODE_BF16, "conv3d_wgrad: a 16-bit dy is bf16 and needs precise = 0");
   MAAVSS_CHECK_ARG(nchunk >= 1, "conv3d_wgrad: nchunk must be >= 1");
   MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_wgrad: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_wgrad: empty output");
   hipStream_t st = (hipStream_t)stream;
   // the two large-M layers use the wide kernel (conv3d_wgrad_wide.hip): every tile staged once / three times
-  if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, st)) {
+  if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, dy16, st)) {
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_wide_kernel");
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * c_in * c_out, 16)), dim3(256), 0, st, ws, dw, nchunk, c_in,
                        c_out, beta);
@@ -518,6 +572,7 @@ extern "C" int maavss_conv3d_wgrad(const float* x, const float* dy, float* dw, f
   if (c_in == CI && c_out == CO) {                                                           \
     if (precise == MODE_F32) launch_wgrad<MODE_F32, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \
     else if (precise == MODE_F16) launch_wgrad<MODE_F16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
+    else if (dy16) launch_wgrad<MODE_BF16, CI, CO, true>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);        \
     else launch_wgrad<MODE_BF16, CI, CO>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_kernel");                                              \
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * CI * CO, 16)), dim3(256), 0, st, ws, dw, nchunk, CI, CO, beta); \

@@ -9,8 +9,8 @@
 // deterministic reduce kernel.
 #include "mma.h"
 
-template <int MODE, int CI, int CO, int KDN>
-__global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int MODE, int CI, int CO, int KDN, bool DY16 = false>
+__global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __restrict__ x, const void* __restrict__ dy_,
                                                                float* __restrict__ partials, int BT, int T, int H, int W,
                                                                int Ho, int Wo, int pad, int tiles_x, int tiles_y,
                                                                int tiles_per_chunk, int nchunk) {
@@ -43,7 +43,9 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   // load -> convert -> store loop) the 13 dependent round trips per tile were 52 % of this kernel's time (scratch build
   // without staging: 2.2 vs 3.3 ms per step over the wgrad launches); one 512-thread workgroup per CU leaves 256
   // VGPRs per lane, so the 56 - 60 staging registers are free.
-  constexpr int XV = KDN * 400 * (CI / 4), DV = 256 * (CO / 4);   // float4s per tile
+  // DY16: dy is stored in the operand format (bf16, by bn_pool_act_bwd): 8 elements per 16-byte vector, copied unconverted
+  constexpr int DVE = DY16 ? 8 : 4;
+  constexpr int XV = KDN * 400 * (CI / 4), DV = 256 * (CO / DVE);   // 16-byte vectors per tile
   constexpr int NX = (XV + 511) / 512, ND = (DV + 511) / 512;
   float4 xr[NX], dr[ND];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
@@ -59,14 +61,17 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
       if (i < XV && tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
         xr[j] = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CI + c4);
     }
-    const float* dp = dy + (int64_t)bt * Ho * Wo * CO;
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
       const int i = tid + j * 512;
-      const int pos = i / (CO / 4), c4 = (i % (CO / 4)) * 4;
+      const int pos = i / (CO / DVE), cv = (i % (CO / DVE)) * DVE;
       const int oy = y0 + pos / 16, ox = x0 + pos % 16;
       dr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < DV && oy < Ho && ox < Wo) dr[j] = *reinterpret_cast<const float4*>(dp + ((int64_t)oy * Wo + ox) * CO + c4);
+      if (i < DV && oy < Ho && ox < Wo) {
+        const int64_t e = (int64_t)bt * Ho * Wo * CO + ((int64_t)oy * Wo + ox) * CO + cv;
+        if constexpr (DY16) dr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(dy_) + e);
+        else dr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + e);
+      }
     }
   };
   auto stash = [&]() __attribute__((always_inline)) {
@@ -82,8 +87,12 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
     for (int j = 0; j < ND; ++j) {
       const int i = tid + j * 512;
       if (i < DV) {
-        E* d = ds + (int64_t)i * 4;   // [pos][CO]
-        d[0] = M::cvt(dr[j].x); d[1] = M::cvt(dr[j].y); d[2] = M::cvt(dr[j].z); d[3] = M::cvt(dr[j].w);
+        E* d = ds + (int64_t)i * DVE;   // [pos][CO]
+        if constexpr (DY16) {
+          *reinterpret_cast<float4*>(d) = dr[j];
+        } else {
+          d[0] = M::cvt(dr[j].x); d[1] = M::cvt(dr[j].y); d[2] = M::cvt(dr[j].z); d[3] = M::cvt(dr[j].w);
+        }
       }
     }
   };
@@ -163,12 +172,12 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   }
 }
 
-template <int MODE, int CI, int CO, int KDN>
-static void launch_wide(const float* x, const float* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
+template <int MODE, int CI, int CO, int KDN, bool DY16 = false>
+static void launch_wide(const float* x, const void* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                         int nchunk, hipStream_t st) {
   using E = typename Mma<MODE>::elem;
   const size_t smem = (KDN * 400 * CI + 256 * CO) * sizeof(E);
-  auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN>;
+  auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN, DY16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
   const int tiles_total = BT * tiles_x * tiles_y;
@@ -179,12 +188,13 @@ static void launch_wide(const float* x, const float* dy, float* ws, int BT, int 
 }
 
 // returns 1 if this (c_in, c_out) pair is handled by the wide kernel (and launches it), 0 otherwise
-int maavss_conv3d_wgrad_wide_try(const float* x, const float* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
-                                 int Wo, int c_in, int c_out, int pad, int mode, hipStream_t st) {
+int maavss_conv3d_wgrad_wide_try(const float* x, const void* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
+                                 int Wo, int c_in, int c_out, int pad, int mode, int dy16, hipStream_t st) {
 #define WIDE(CI, CO, KDN)                                                                                      \
   if (c_in == CI && c_out == CO) {                                                                             \
     if (mode == MODE_F32) launch_wide<MODE_F32, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \
     else if (mode == MODE_F16) launch_wide<MODE_F16, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st); \
+    else if (dy16) launch_wide<MODE_BF16, CI, CO, KDN, true>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);      \
     else launch_wide<MODE_BF16, CI, CO, KDN>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);                      \
     return 1;                                                                                                  \
   }

@@ -55,8 +55,15 @@ def conv3d_prep(w, mode, precise):
 
 
 def conv3d_igemm(x, wt, c_out, pad, precise, want_stats=False):
-    """x [B,T,H,W,Ci] -> y [B,T,Ho,Wo,c_out] (+ BatchNorm partial sums [nblk,2,c_out])."""
-    _f32(x)
+    """x [B,T,H,W,Ci] -> y [B,T,Ho,Wo,c_out] (+ BatchNorm partial sums [nblk,2,c_out]).  x is f32, or already in the
+    16-bit MFMA operand format of `precise` (float16 for MODE_F16, bfloat16 for MODE_BF16: copied, not converted)."""
+    _lib.require_cuda(x)
+    x16 = x.dtype != torch.float32
+    if x16:
+        want = {MODE_F16: torch.float16, MODE_BF16: torch.bfloat16}.get(int(precise))
+        assert x.dtype == want and x.is_contiguous(), "16-bit conv3d input must match the MFMA mode"
+    else:
+        _f32(x)
     b, t, h, w, ci = x.shape
     ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
     y = torch.empty(b, t, ho, wo, c_out, device=x.device, dtype=torch.float32)
@@ -64,7 +71,7 @@ def conv3d_igemm(x, wt, c_out, pad, precise, want_stats=False):
     if want_stats:
         nblk = ((wo + 15) // 16) * ((ho + 15) // 16) * b * t
         part = torch.empty(nblk, 2, c_out, device=x.device, dtype=torch.float32)
-    call("maavss_conv3d_igemm", ptr(x), ptr(wt), ptr(y), ptr(part), b, t, h, w, ci, c_out, pad, int(precise),
+    call("maavss_conv3d_igemm", ptr(x), ptr(wt), ptr(y), ptr(part), b, t, h, w, ci, c_out, pad, int(precise), int(x16),
          stream_ptr())
     return y, part
 
@@ -81,7 +88,13 @@ def wgrad_chunks(b, t, ho, wo, ci=64, co=64):
 
 
 def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
-    _f32(x, dy, dw)
+    """dy: f32, or bfloat16 (bn_pool_act_bwd(dy_bf16=True)) with precise = MODE_BF16"""
+    _f32(x, dw)
+    dy16 = dy.dtype == torch.bfloat16
+    if dy16:
+        assert int(precise) == MODE_BF16 and dy.is_contiguous() and dy.is_cuda
+    else:
+        _f32(dy)
     b, t, h, w, ci = x.shape
     co = dy.shape[-1]
     ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
@@ -93,7 +106,7 @@ def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
         dw = torch.empty(co, ci, 3, 5, 5, device=x.device, dtype=torch.float32)
         beta = 0
     call("maavss_conv3d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), nchunk, b, t, h, w, ci, co, pad, int(beta),
-         int(precise), stream_ptr())
+         int(precise), int(dy16), stream_ptr())
     return dw
 
 
@@ -190,8 +203,9 @@ def cl_strides(t, hp, wp, c):
     return (t * hp * wp * c, hp * wp * c, c, 1)
 
 
-def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=None):
-    """y [B,T,H,W,C] -> out (default channels-last [B,T,H//p,W//p,C]) and argmax (uint8) when pool > 1."""
+def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=None, want16=False):
+    """y [B,T,H,W,C] -> out (default channels-last [B,T,H//p,W//p,C]) and argmax (uint8) when pool > 1.
+    want16: also return an IEEE-half copy of the pooled activation (the next Conv3d's forward MFMA operand)."""
     _f32(y, mean, invstd, gamma, beta)
     b, t, h, w, c = y.shape
     hp, wp = h // pool, w // pool
@@ -199,13 +213,16 @@ def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=N
         out = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.float32)
         strides = cl_strides(t, hp, wp, c)
     arg = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.uint8) if pool > 1 else None
+    out16 = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.float16) if want16 else None
     call("maavss_bn_pool_act_fwd", ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(arg), b, t, h,
-         w, c, pool, act, *[int(s) for s in strides], stream_ptr())
+         w, c, pool, act, *[int(s) for s in strides], ptr(out16), stream_ptr())
+    if want16:
+        return out, arg, out16
     return out, arg
 
 
 def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,
-                    accumulate=False, dy=None, coef_only=False, beta=None, reduce_fn=None):
+                    accumulate=False, dy=None, coef_only=False, beta=None, reduce_fn=None, dy_bf16=False):
     """`reduce_fn` (global-batch BatchNorm under data parallelism): all-reduces the [2C+1] double sums between the
     reduction and the dx pass; dgamma / dbeta keep this rank's sums (the gradient all-reduce adds the ranks)."""
     _f32(y, mean, invstd, gamma)
@@ -216,7 +233,7 @@ def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=N
     nblk = query("maavss_bn_stats_nblk", b * t * hp * wp)
     ws = torch.empty(2 * c * nblk + 3 * c, device=y.device, dtype=torch.float32)
     if dy is None and not coef_only:
-        dy = torch.empty_like(y)
+        dy = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16 if dy_bf16 else torch.float32)
     _f32(beta)
     if reduce_fn is not None:
         geom = (b, t, h, w, c, pool, act, *[int(s) for s in strides], stream_ptr())
@@ -227,11 +244,11 @@ def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=N
         reduce_fn(glob)
         coef = ws[2 * c * nblk:]
         call("maavss_bn_pool_act_bwd_finish", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-             ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(local), ptr(glob), ptr(coef), *geom)
+             ptr(dy), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(local), ptr(glob), ptr(coef), *geom[:-1], int(dy_bf16), geom[-1])
         return coef.view(3, c) if coef_only else dy
     call("maavss_bn_pool_act_bwd", ptr(dout), ptr(out), ptr(arg), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(dy),
          ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), b, t, h, w, c, pool, act, *[int(s) for s in strides],
-         stream_ptr())
+         int(dy_bf16), stream_ptr())
     if coef_only:      # dgamma / dbeta done; the consumer folds dx in (conv3d_c1_wgrad_bn): [3, C] coefficients
         return ws[2 * c * nblk:].view(3, c)
     return dy

@@ -116,6 +116,59 @@ def test_conv3d_igemm_fwd_dgrad_wgrad(ci, co, pad, b, t, h, w, precise):
     close(dw2, 2 * gw_ref, 2e-4, 4e-4 * scale + 1e-5)
 
 
+@pytest.mark.parametrize("ci,co,pad,b,t,h,w", [
+    (16, 32, 2, 1, 3, 20, 36),     # C_in = 16 / 32: LDS-DMA halo (zero source = the padded tail of the weight rows)
+    (32, 64, 2, 2, 2, 16, 16),
+    (64, 64, 2, 1, 4, 28, 28),     # C_in = 64: register prefetch of 16-bit vectors
+    (64, 16, 3, 2, 3, 10, 10),
+    (32, 16, 2, 2, 2, 23, 17),     # input-gradient shape of the first MFMA layer, ragged tiles
+])
+def test_conv3d_16bit_operand_storage_is_bit_identical(ci, co, pad, b, t, h, w):
+    """Operands that arrive already in the MFMA format (x as IEEE half / bf16, dy as bf16: rounded once by the producer
+    kernels bn_pool_act_fwd / bn_pool_act_bwd) must give exactly the result of the f32-input path, which applies the same
+    rounding while staging."""
+    from maavss_amd import ops
+    x = to_cl(rnd(b, ci, t, h, w, seed=1)).cuda()
+    wgt = rnd(co, ci, 3, 5, 5, seed=2, scale=(ci * 75) ** -0.5).cuda()
+    for mode, tdt in ((ops.MODE_F16, torch.float16), (ops.MODE_BF16, torch.bfloat16)):
+        wt = ops.conv3d_prep(wgt, 0, mode)
+        y32, p32 = ops.conv3d_igemm(x, wt, co, pad, mode, want_stats=True)
+        y16, p16 = ops.conv3d_igemm(x.to(tdt), wt, co, pad, mode, want_stats=True)
+        assert torch.equal(y32, y16) and torch.equal(p32, p16), (ci, co, mode)
+    ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
+    dy = rnd(b, t, ho, wo, co, seed=3).cuda()
+    if (ci, co) in ((16, 32), (32, 64), (64, 64), (64, 16)):                          # the model's weight-gradient shapes
+        dw32 = ops.conv3d_wgrad(x, dy, pad, ops.MODE_BF16)
+        dw16 = ops.conv3d_wgrad(x, dy.to(torch.bfloat16), pad, ops.MODE_BF16)
+        assert torch.equal(dw32, dw16)
+    if (co, ci) in ((32, 16), (64, 32), (64, 64), (16, 64), (16, 32), (32, 64)):      # dgrad instantiations
+        wtd = ops.conv3d_prep(wgt, 1, ops.MODE_BF16)
+        dx32, _ = ops.conv3d_igemm(dy, wtd, ci, 4 - pad, ops.MODE_BF16)
+        dx16, _ = ops.conv3d_igemm(dy.to(torch.bfloat16), wtd, ci, 4 - pad, ops.MODE_BF16)
+        assert torch.equal(dx32, dx16)
+
+
+def test_bn_pool_act_16bit_side_outputs():
+    """bn_pool_act_fwd's IEEE-half copy == the f32 output rounded; bn_pool_act_bwd(dy_bf16) == its f32 dy rounded"""
+    from maavss_amd import ops
+    b, t, c, h, w, pool = 2, 3, 32, 12, 20, 2
+    y = rnd(b, t, h, w, c, seed=1).cuda()
+    part = ops.bn_stats(y, c)
+    mean, invstd = ops.bn_finalize(part, b * t * h * w)
+    gamma, beta = (1 + 0.3 * rnd(c, seed=2)).cuda(), (0.2 * rnd(c, seed=3)).cuda()
+    out, arg, out16 = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0, want16=True)
+    out_b, arg_b = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0)
+    assert torch.equal(out, out_b) and torch.equal(arg, arg_b)
+    assert out16.dtype == torch.float16 and torch.equal(out16, out.half())
+    dout = rnd(*out.shape, seed=4).cuda()
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy32 = ops.bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, 0, dgamma=dg, dbeta=db, beta=beta)
+    dg2, db2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy16 = ops.bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, 0, dgamma=dg2, dbeta=db2, beta=beta, dy_bf16=True)
+    assert dy16.dtype == torch.bfloat16 and torch.equal(dy16, dy32.bfloat16())
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
 def test_conv3d_c1():
     from maavss_amd import ops
     b, t, h, w = 2, 3, 40, 24
