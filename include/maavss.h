@@ -81,7 +81,8 @@ int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, in
 /* first layer (C_in = 1, pad 2): x [B][T][H][W], w [16][1][3][5][5], w16_ws 1200 floats scratch,
  * y [B][T][H][W][16]; stat_partials as above; wgrad ws = nchunk*1200 floats. */
 int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B, int T,
-                         int H, int W, void* stream);
+                         int H, int W, int precise /* 1: exact-f32 VALU convolution; 2: IEEE-half operands on the MFMA
+                         (25 taps of a kd plane = one 32-deep step), f32 accumulation */, void* stream);
 int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
                            int W, int beta, void* stream);
 /* The same with the first layer's BatchNorm / max-pool / LeakyReLU backward folded into the loader: y is the conv output,

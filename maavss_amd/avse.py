@@ -482,7 +482,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             conv, bn = self._vis(i)
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
             if i == 0:
-                y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=train)
+                y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=train, precise=pr)
             else:
                 wt = ops.conv3d_prep(conv.weight.detach(), 0, pr)
                 y, part = ops.conv3d_igemm(act_in if act_in16 is None else act_in16, wt, co, pad, pr, want_stats=train)

@@ -14,6 +14,7 @@
 //                    channels-last LDS tiles with ds_read_b64_tr_b16 (hardware transpose).  A workgroup
 //                    owns one (kd,kh) and the 5 kw taps, walks a chunk of position tiles and writes a
 //                    partial; a second kernel sums the chunks (deterministic, no atomics).
+#include <type_traits>
 #include "mma.h"
 
 // --------------------------------------------------------------------------------------------
@@ -645,6 +646,103 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
   }
 }
 
+// The same layer on the matrix pipe (16-bit path): implicit GEMM  y[pos][co] = sum_k A[pos][k] W[k][co]  with, per kd plane,
+// k = kh * 5 + kw (25 taps padded to one 32-deep MFMA step, zero weights in the pad).  One workgroup = a 16x16 output tile of one
+// (b, t) plane (as the f32 kernel); a wave owns 4 rows of 16 positions = 4 M-tiles.  The A fragment of lane (position l16,
+// k group g) is 8 taps of the IEEE-half halo image [3][20][24]: eight ds_read_u16 whose per-lane part (tap offset of
+// (g, j), position) sits in 8 address registers computed once and whose (kd, row) part is an immediate -- no address
+// arithmetic in the loop.  12 MFMAs per wave and tile instead of 300 packed FMAs per lane: the f32 VALU kernel ran at 62 of the
+// 157 TFLOP/s vector peak (0.99 ms per step); this one is bound by its 1.6 GB output.
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 float* __restrict__ y, float* __restrict__ stat_partials,
+                                                                 int n_bt, int T, int H, int W) {
+  __shared__ __attribute__((aligned(16))) unsigned short halo[3][20][24];
+  __shared__ float red[4][2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const TileId tile = xcd_tile((W + 15) / 16, (H + 15) / 16, (int64_t)((W + 15) / 16) * ((H + 15) / 16) * n_bt);
+  if (!tile.valid) return;
+  const int x0 = tile.tx * 16, y0 = tile.ty * 16, bt = tile.bt, t = bt % T;
+  for (int i = tid; i < 1200; i += 256) {
+    const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
+    const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
+    float v = 0.f;
+    if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(bt + kd - 1) * H + iy) * W + ix];
+    halo[kd][r][c] = Mma<MODE_F16>::cvt(v);
+  }
+  // weight fragments (B operand): lane (co = l16, g) holds W[co][kd][k = 8 g + j], j = 0..7, zero for k >= 25
+  bf16x8 fb[3];
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd) {
+    unsigned wq[4];
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const int k0 = 8 * g + 2 * jp;
+      const float a = k0 < 25 ? w[l16 * 75 + kd * 25 + k0] : 0.f, b = k0 + 1 < 25 ? w[l16 * 75 + kd * 25 + k0 + 1] : 0.f;
+      wq[jp] = pack2<MODE_F16>(a, b);
+    }
+    fb[kd] = __builtin_bit_cast(bf16x8, make_uint4(wq[0], wq[1], wq[2], wq[3]));
+  }
+  // per-lane byte addresses of the 8 taps of this lane's k group for position (row 4 wv, column l16) of kd plane 0
+  unsigned addr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int k = 8 * g + j;
+    k = k < 25 ? k : 0;                    // padded k: any in-range halo element (its weight is zero, the halo is finite)
+    const int kh = k / 5, kw = k % 5;
+    addr[j] = (unsigned)(((4 * wv + kh) * 24 + l16 + kw) * 2);      // byte offset inside the halo image
+  }
+  __syncthreads();
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one M-tile (row i) x one kd plane: the (kd, row) displacement is an instruction immediate
+  auto step = [&](auto kd_c, auto i_c) __attribute__((always_inline)) {
+    constexpr int kd = decltype(kd_c)::value, i = decltype(i_c)::value;
+    constexpr int off = (kd * 20 + i) * 24 * 2;       // bytes: kd plane 20 x 24 halves, row 24 halves
+    // eight zero-extending 16-bit reads (per-lane part of the address in addr[], (kd, row) part a compile-time displacement),
+    // paired into the four fragment registers
+    const char* hb = reinterpret_cast<const char*>(&halo[0][0][0]) + off;
+    const unsigned e0 = *reinterpret_cast<const unsigned short*>(hb + addr[0]), e1 = *reinterpret_cast<const unsigned short*>(hb + addr[1]);
+    const unsigned e2 = *reinterpret_cast<const unsigned short*>(hb + addr[2]), e3 = *reinterpret_cast<const unsigned short*>(hb + addr[3]);
+    const unsigned e4 = *reinterpret_cast<const unsigned short*>(hb + addr[4]), e5 = *reinterpret_cast<const unsigned short*>(hb + addr[5]);
+    const unsigned e6 = *reinterpret_cast<const unsigned short*>(hb + addr[6]), e7 = *reinterpret_cast<const unsigned short*>(hb + addr[7]);
+    const unsigned a0 = e0 | (e1 << 16), a1 = e2 | (e3 << 16), a2 = e4 | (e5 << 16), a3 = e6 | (e7 << 16);
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
+    Mma<MODE_F16>::mma(acc[i], fa, fb[kd]);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
+  step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
+  step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
+  // ---- epilogue: lane holds co = l16 of positions (row 4 wv + i, column 4 g + r)
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oy = y0 + 4 * wv + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ox = x0 + 4 * g + r;
+      if (oy < H && ox < W) {
+        const float v = acc[i][r];
+        y[(((int64_t)bt * H + oy) * W + ox) * 16 + l16] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (stat_partials != nullptr) {
+    s1 = rows4_sum(s1);
+    s2 = rows4_sum(s2);
+    if (g == 0) { red[wv][0][l16] = s1; red[wv][1][l16] = s2; }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, c = tid & 15;
+      stat_partials[tile.lin * 32 + tid] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+  }
+}
+
 // reference layout [16][1][3][5][5] -> [75][16]
 __global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __restrict__ w16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -773,10 +871,17 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float
 }
 
 extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B,
-                                    int T, int H, int W, void* stream) {
+                                    int T, int H, int W, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && w && w16_ws && y, "conv3d_c1_fwd: null pointer");
   MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "conv3d_c1_fwd: empty problem");
+  MAAVSS_CHECK_ARG(precise == MODE_F32 || precise == MODE_F16, "conv3d_c1_fwd: mode must be 1 (exact f32 VALU) or 2 (IEEE-half MFMA)");
   hipStream_t st = (hipStream_t)stream;
+  if (precise == MODE_F16) {
+    hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel, dim3(xcd_grid((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T)), dim3(256), 0, st, x, w, y,
+                       stat_partials, B * T, T, H, W);
+    MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_mfma_kernel");
+    return MAAVSS_OK;
+  }
   hipLaunchKernelGGL(conv3d_c1_prep_kernel, dim3(5), dim3(256), 0, st, w, w16_ws);
   hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(xcd_grid((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T)), dim3(256), 0, st, x, w16_ws, y,
                      stat_partials, B * T, T, H, W);

@@ -110,8 +110,8 @@ def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
     return dw
 
 
-def conv3d_c1_fwd(x, w, want_stats=False):
-    """x [B,T,H,W] (C=1), w [16,1,3,5,5] -> y [B,T,H,W,16]."""
+def conv3d_c1_fwd(x, w, want_stats=False, precise=MODE_F32):
+    """x [B,T,H,W] (C=1), w [16,1,3,5,5] -> y [B,T,H,W,16].  precise: MODE_F32 (exact VALU) or MODE_F16 (MFMA)."""
     _f32(x, w)
     b, t, h, wd = x.shape
     y = torch.empty(b, t, h, wd, 16, device=x.device, dtype=torch.float32)
@@ -119,7 +119,7 @@ def conv3d_c1_fwd(x, w, want_stats=False):
     part = None
     if want_stats:
         part = torch.empty(((wd + 15) // 16) * ((h + 15) // 16) * b * t, 2, 16, device=x.device, dtype=torch.float32)
-    call("maavss_conv3d_c1_fwd", ptr(x), ptr(w), ptr(w16), ptr(y), ptr(part), b, t, h, wd, stream_ptr())
+    call("maavss_conv3d_c1_fwd", ptr(x), ptr(w), ptr(w16), ptr(y), ptr(part), b, t, h, wd, int(precise), stream_ptr())
     return y, part
 
 

@@ -142,6 +142,17 @@ class _Conv3dEmu(nn.Conv3d):
         return _Conv3d16bit.apply(x, self.weight, self.padding[1])
 
 
+class _Conv3dEmuFwd(nn.Conv3d):
+    """layer 0 (C_in = 1) of the HIP 16-bit path: IEEE-half operands on the MFMA in the forward pass, exact-f32 weight
+    gradient (the network input needs no gradient)"""
+
+    def forward(self, x):
+        xh, wh = x.half().float(), self.weight.half().float()
+        # value of the rounded-operand convolution, gradient of the unrounded one w.r.t. the weight
+        exact = F.conv3d(x, self.weight, padding=self.padding)
+        return exact + (F.conv3d(xh, wh, padding=self.padding) - exact).detach()
+
+
 class AVFusionFramesRef(nn.Module):
     """Oracle twin of the reference's AV_Fusion_Model_Frames (same ctor args,
     same forward contract, same state_dict keys).  `emulate_16bit=True` (not in the reference) rounds the operands
@@ -168,7 +179,7 @@ class AVFusionFramesRef(nn.Module):
         pads = [2, 2, 2, 2, 3]
         mods = []
         for i in range(5):
-            conv = _Conv3dEmu if (emulate_16bit and i > 0) else nn.Conv3d     # layer 0 (C_in = 1) runs in f32 on the GPU too
+            conv = (_Conv3dEmu if i > 0 else _Conv3dEmuFwd) if emulate_16bit else nn.Conv3d
             mods += [conv(chans[i], chans[i + 1], (3, 5, 5), 1, (1, pads[i], pads[i]), bias=False),
                      nn.BatchNorm3d(chans[i + 1]),
                      nn.MaxPool3d((1, pools[i], pools[i])),

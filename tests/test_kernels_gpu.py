@@ -184,6 +184,13 @@ def test_conv3d_c1():
     np.testing.assert_allclose(s[0].numpy(), y_ref.detach().sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
     dw = ops.conv3d_c1_wgrad(xc, to_cl(dy).cuda())
     close(dw, gw_ref, 1e-4, 1e-4 * gw_ref.abs().max().item())
+    # the MFMA form of the forward pass (IEEE-half operands, f32 accumulation) against torch on the same rounded operands
+    y16, part16 = ops.conv3d_c1_fwd(xc, wgt.detach().cuda(), want_stats=True, precise=ops.MODE_F16)
+    y16_ref = F.conv3d(x.detach().half().float(), wgt.detach().half().float(), padding=(1, 2, 2))
+    close(from_cl(y16), y16_ref, 2e-5, 2e-5)
+    s16 = part16.sum(0).cpu()
+    np.testing.assert_allclose(s16[0].numpy(), y16_ref.sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(s16[1].numpy(), (y16_ref * y16_ref).sum((0, 2, 3, 4)).numpy(), rtol=1e-3, atol=1e-2)
 
 
 # ----------------------------------------------------------------------------------------------- BN + pool + act
