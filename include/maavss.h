@@ -90,7 +90,8 @@ int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw, float* ws
  * coefficients maavss_bn_pool_act_bwd leaves at ws + 2*C*maavss_bn_stats_nblk(rows) when called with dy = NULL. */
 int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout, const float* out, const void* argmax,
                               const float* mean, const float* invstd, const float* coef, int pool, float* dw, float* ws,
-                              int nchunk, int B, int T, int H, int W, int beta, void* stream);
+                              int nchunk, int B, int T, int H, int W, int beta,
+                              int precise /* 1: exact-f32 VALU; 0: bf16 operands on the MFMA (positions = K dimension) */, void* stream);
 
 /* ---- K9 BatchNorm (train mode) + MaxPool(1,p,p) + LeakyReLU / BatchNorm2d + Tanh -----------------
  * avse_model_final.py:35-37,...,55-57 (pool before activation) and :103-104 (pool = 1, act = 1).

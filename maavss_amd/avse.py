@@ -656,7 +656,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 if need.get(wname, False):
                     buf, beta = gbuf(wname)
                     ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
-                                           dw=buf, beta=beta)
+                                           dw=buf, beta=beta, precise=pr_conv)
                     out_grads[wname] = buf
                 continue
             # 16-bit path: dy is written as bf16 -- what both of its consumers (weight gradient, input gradient) round it to

@@ -863,6 +863,125 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
     partials[(int64_t)chunk * 1200 + i] = red[i] + red[1200 + i] + red[2400 + i] + red[3600 + i];
 }
 
+// The first layer's weight gradient on the matrix pipe (16-bit path), BatchNorm / max-pool / LeakyReLU backward fused as in
+// conv3d_c1_wgrad_kernel<true>:  dW[tap][co] = sum over positions of x[pos + tap] * dy[pos][co]  as an MFMA product with the
+// 75 taps as rows (5 tiles of 16, the last 5 rows unused), co as columns and the POSITION as the K dimension (32 positions =
+// two tile rows per step).  Per 16x16 tile: the x halo is staged as bf16 [3][20][24]; dy is formed in f32 from the pooled
+// gradient exactly as before, rounded to bf16 and stored TRANSPOSED [co][pos] so that a B fragment (8 consecutive positions
+// of one channel) is one 16-byte LDS read; an A fragment of lane (tap, k group) is 8 consecutive halo columns of the tap's
+// (kd, kh) row starting at column kw (eight 16-bit reads).  A wave takes 2 of the tile's 8 K-steps for all 5 tap tiles and
+// keeps its 5 accumulators across the chunk's tiles; the waves are summed once per chunk.  75 FMAs per (position, channel)
+// on the VALU become 5 MFMAs per 32 positions: the f32 kernel took 1.55 ms per step, this one is bound by reading y (1.6 GB).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3d_c1_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ yconv,
+                                                                   float* __restrict__ partials, int T, int H, int W, int tiles_x,
+                                                                   int tiles_y, int BT, int tiles_per_chunk, int nchunk, C1BnArgs bn) {
+  constexpr int DYS = 256 + 8;                                        // dyT row stride (elements): 528 B, 16-byte aligned
+  __shared__ __attribute__((aligned(16))) char smem[4 * 80 * 16 * 4];  // max(halo + dyT = 2880 + 8448 B, final reduction 20480 B)
+  unsigned short (*halo)[20][24] = reinterpret_cast<unsigned short (*)[20][24]>(smem);
+  unsigned short* dyT = reinterpret_cast<unsigned short*>(smem + 3 * 20 * 24 * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int chunk = (blockIdx.x & 7) * ((nchunk + 7) / 8) + (blockIdx.x >> 3);
+  if (chunk >= nchunk) return;
+  // per-lane halo byte offsets of the 5 tap tiles: tap (kd, kh, kw), plus this lane's k group (row g >> 1, column 8 (g & 1))
+  int abase[5];
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt) {
+    int tap = 16 * mt + l16;
+    tap = tap < 75 ? tap : 74;                                       // rows 75..79 of the last tile: computed, never stored
+    const int kd = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
+    abase[mt] = (((kd * 20 + kh + (g >> 1)) * 24) + kw + 8 * (g & 1)) * 2;
+  }
+  f32x4 acc[5];
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tile_beg = chunk * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y), t = bt % T;
+    const int x0 = tx * 16, y0 = ty * 16;
+    __syncthreads();
+    // dy formation: all of a thread's 16 loads (4 positions x {y, argmax, dout, out}) are issued before the first is used, ahead of the halo's loads --
+    // with the conditional, dependent loads of the f32 kernel's loop a tile took 12 us of chained memory round trips.
+    // Coordinates are clamped instead of predicated (edge tiles: the values are discarded below).
+    float4 yv[4], dv[4], ov[4];
+    uchar4 am[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 256, pos = i >> 2, cc = (i & 3) * 4;
+      const int oy = min(y0 + (pos >> 4), H - 1), ox = min(x0 + (pos & 15), W - 1);
+      const int py = min(oy / bn.pool, bn.Hp - 1), px = min(ox / bn.pool, bn.Wp - 1);
+      const int64_t pp = (((int64_t)bt * bn.Hp + py) * bn.Wp + px) * 16 + cc;
+      yv[it] = *reinterpret_cast<const float4*>(yconv + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
+      am[it] = *reinterpret_cast<const uchar4*>(bn.argmax + pp);
+      dv[it] = *reinterpret_cast<const float4*>(bn.dout + pp);
+      ov[it] = *reinterpret_cast<const float4*>(bn.out + pp);
+    }
+    for (int i = tid; i < 1200; i += 256) {
+      const int d = i / 400, r = (i % 400) / 20, c = i % 20;
+      const int tt = t + d - 1, iy = y0 + r - 2, ix = x0 + c - 2;
+      float v = 0.f;
+      if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(bt + d - 1) * H + iy) * W + ix];
+      halo[d][r][c] = f2bf(v);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 256, pos = i >> 2, cc = (i & 3) * 4;
+      const int oy = y0 + (pos >> 4), ox = x0 + (pos & 15);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < H && ox < W) {
+        // same arithmetic as bn_pool_act_bwd_dx_kernel (bn_pool.hip), LeakyReLU(0.01) + max pool
+        const int py = oy / bn.pool, px = ox / bn.pool;
+        float gg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (py < bn.Hp && px < bn.Wp) {
+          const int here = (oy - py * bn.pool) * bn.pool + (ox - px * bn.pool);
+          if (am[it].x == here) gg[0] = dv[it].x * (ov[it].x > 0.f ? 1.f : 0.01f);
+          if (am[it].y == here) gg[1] = dv[it].y * (ov[it].y > 0.f ? 1.f : 0.01f);
+          if (am[it].z == here) gg[2] = dv[it].z * (ov[it].z > 0.f ? 1.f : 0.01f);
+          if (am[it].w == here) gg[3] = dv[it].w * (ov[it].w > 0.f ? 1.f : 0.01f);
+        }
+        const float4 mu = *reinterpret_cast<const float4*>(bn.mean + cc), is = *reinterpret_cast<const float4*>(bn.invstd + cc);
+        const float4 k0 = *reinterpret_cast<const float4*>(bn.coef + cc), k1 = *reinterpret_cast<const float4*>(bn.coef + 16 + cc);
+        const float4 k2 = *reinterpret_cast<const float4*>(bn.coef + 32 + cc);
+        v.x = k0.x * (gg[0] - k1.x - (yv[it].x - mu.x) * is.x * k2.x);
+        v.y = k0.y * (gg[1] - k1.y - (yv[it].y - mu.y) * is.y * k2.y);
+        v.z = k0.z * (gg[2] - k1.z - (yv[it].z - mu.z) * is.z * k2.z);
+        v.w = k0.w * (gg[3] - k1.w - (yv[it].w - mu.w) * is.w * k2.w);
+      }
+      dyT[(cc + 0) * DYS + pos] = f2bf(v.x);
+      dyT[(cc + 1) * DYS + pos] = f2bf(v.y);
+      dyT[(cc + 2) * DYS + pos] = f2bf(v.z);
+      dyT[(cc + 3) * DYS + pos] = f2bf(v.w);
+    }
+    __syncthreads();
+    const char* hb0 = reinterpret_cast<const char*>(&halo[0][0][0]);
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      const int ks = wv * 2 + ksl;                                   // positions 32 ks .. 32 ks + 31 = tile rows 2 ks, 2 ks + 1
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(dyT + l16 * DYS + 32 * ks + 8 * g);
+      const char* hb = hb0 + ks * (2 * 24 * 2);
+#pragma unroll
+      for (int mt = 0; mt < 5; ++mt) {
+        const unsigned short* ap = reinterpret_cast<const unsigned short*>(hb + abase[mt]);
+        const unsigned a0 = ap[0] | ((unsigned)ap[1] << 16), a1 = ap[2] | ((unsigned)ap[3] << 16);
+        const unsigned a2 = ap[4] | ((unsigned)ap[5] << 16), a3 = ap[6] | ((unsigned)ap[7] << 16);
+        Mma<MODE_BF16>::mma(acc[mt], __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3)), fb);
+      }
+    }
+  }
+  // ---- sum the four waves: lane (co = l16, g) holds taps 16 mt + 4 g + r
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                        // [4 waves][80 taps][16 co]
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wv * 80 + 16 * mt + 4 * g + r) * 16 + l16] = acc[mt][r];
+  __syncthreads();
+  for (int i = tid; i < 1200; i += 256) {     // i = c * 75 + tap: [chunk][c][tap]
+    const int c = i / 75, tap = i % 75;
+    partials[(int64_t)chunk * 1200 + i] = red[tap * 16 + c] + red[(80 + tap) * 16 + c] + red[(160 + tap) * 16 + c] + red[(240 + tap) * 16 + c];
+  }
+}
+
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
   bool owner;
   int i;
@@ -890,11 +1009,14 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
 }
 
 static int c1_wgrad_launch(const float* x, const float* dy_or_y, float* dw, float* ws, int nchunk, int B, int T, int H, int W, int beta,
-                           const C1BnArgs* bn, hipStream_t st) {
+                           const C1BnArgs* bn, hipStream_t st, bool mfma = false) {
   const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
   const int tiles_total = B * T * tiles_x * tiles_y;
   C1BnArgs none = {};
-  if (bn)
+  if (bn && mfma)
+    hipLaunchKernelGGL(conv3d_c1_wgrad_mfma_kernel, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy_or_y, ws, T, H, W, tiles_x, tiles_y,
+                       B * T, cdiv(tiles_total, nchunk), nchunk, *bn);
+  else if (bn)
     hipLaunchKernelGGL(conv3d_c1_wgrad_kernel<true>, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, st, x, dy_or_y, ws, T, H, W, tiles_x, tiles_y,
                        B * T, cdiv(tiles_total, nchunk), nchunk, *bn);
   else
@@ -915,11 +1037,12 @@ extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw
 
 extern "C" int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout, const float* out, const void* argmax,
                                          const float* mean, const float* invstd, const float* coef, int pool, float* dw, float* ws,
-                                         int nchunk, int B, int T, int H, int W, int beta, void* stream) {
+                                         int nchunk, int B, int T, int H, int W, int beta, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && y && dout && out && argmax && mean && invstd && coef && dw && ws, "conv3d_c1_wgrad_bn: null pointer");
+  MAAVSS_CHECK_ARG(precise == MODE_F32 || precise == MODE_BF16, "conv3d_c1_wgrad_bn: mode must be 1 (exact f32 VALU) or 0 (bf16 MFMA)");
   MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn: bad sizes (pool must be 2 or 3)");
   C1BnArgs bn;
   bn.dout = dout; bn.out = out; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
   bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
-  return c1_wgrad_launch(x, y, dw, ws, nchunk, B, T, H, W, beta, &bn, (hipStream_t)stream);
+  return c1_wgrad_launch(x, y, dw, ws, nchunk, B, T, H, W, beta, &bn, (hipStream_t)stream, precise == MODE_BF16);
 }

@@ -4,6 +4,8 @@ Tensors are torch CUDA tensors used purely as device-memory handles: every funct
 device pointers + explicit sizes + the current HIP stream to libmaavss_hip.so.  No torch math here.
 Layouts: visual activations channels-last [B,T,H,W,C]; STFT-encoder activations NHWC.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -136,18 +138,19 @@ def conv3d_c1_wgrad(x, dy, dw=None, beta=0, nchunk=None):
     return dw
 
 
-def conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, dw=None, beta=0, nchunk=None):
+def conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, dw=None, beta=0, nchunk=None, precise=MODE_F32):
     """first-layer weight gradient straight from the pooled gradient: BN / max-pool / LeakyReLU backward in the loader."""
     _f32(x, y, dout, out, mean, invstd, coef, dw)
     b, t, h, wd = x.shape
     assert y.shape == (b, t, h, wd, 16) and dout.is_contiguous() and out.is_contiguous()
     if nchunk is None:
-        nchunk = max(1, min(1024, (b * t * ((h + 15) // 16) * ((wd + 15) // 16)) // 2))
+        cap = int(os.environ.get("MAAVSS_C1_NCHUNK", "1024"))
+        nchunk = max(1, min(cap, (b * t * ((h + 15) // 16) * ((wd + 15) // 16)) // 2))
     ws = torch.empty(nchunk * 1200, device=x.device, dtype=torch.float32)
     if dw is None:
         dw, beta = torch.empty(16, 1, 3, 5, 5, device=x.device, dtype=torch.float32), 0
     call("maavss_conv3d_c1_wgrad_bn", ptr(x), ptr(y), ptr(dout), ptr(out), ptr(arg), ptr(mean), ptr(invstd), ptr(coef), pool, ptr(dw),
-         ptr(ws), nchunk, b, t, h, wd, int(beta), stream_ptr())
+         ptr(ws), nchunk, b, t, h, wd, int(beta), int(precise), stream_ptr())
     return dw
 
 

@@ -142,15 +142,29 @@ class _Conv3dEmu(nn.Conv3d):
         return _Conv3d16bit.apply(x, self.weight, self.padding[1])
 
 
-class _Conv3dEmuFwd(nn.Conv3d):
-    """layer 0 (C_in = 1) of the HIP 16-bit path: IEEE-half operands on the MFMA in the forward pass, exact-f32 weight
-    gradient (the network input needs no gradient)"""
+class _Conv3d16bitL0(torch.autograd.Function):
+    """layer 0 (C_in = 1) of the HIP 16-bit path: IEEE-half operands on the MFMA in the forward pass; weight gradient with x and
+    dy rounded to bf16 (conv3d_c1_wgrad_mfma_kernel); the network input needs no gradient"""
 
+    @staticmethod
+    def forward(ctx, x, w, pad):
+        ctx.save_for_backward(x, w)
+        ctx.pad = pad
+        return F.conv3d(x.half().float(), w.half().float(), padding=(1, pad, pad))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        bf = lambda t: t.to(torch.bfloat16).float()     # noqa: E731
+        pad = (1, ctx.pad, ctx.pad)
+        dx = torch.nn.grad.conv3d_input(x.shape, w, dy, padding=pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv3d_weight(bf(x), w.shape, bf(dy), padding=pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class _Conv3dEmuFwd(nn.Conv3d):
     def forward(self, x):
-        xh, wh = x.half().float(), self.weight.half().float()
-        # value of the rounded-operand convolution, gradient of the unrounded one w.r.t. the weight
-        exact = F.conv3d(x, self.weight, padding=self.padding)
-        return exact + (F.conv3d(xh, wh, padding=self.padding) - exact).detach()
+        return _Conv3d16bitL0.apply(x, self.weight, self.padding[1])
 
 
 class AVFusionFramesRef(nn.Module):

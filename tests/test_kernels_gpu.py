@@ -248,6 +248,31 @@ def test_bn_pool_act(c, pool, act, h, w):
         close(db2, gb2, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("b,t,h,w", [(2, 3, 40, 24), (1, 2, 33, 50)])
+def test_conv3d_c1_wgrad_bn_mfma_matches_the_f32_kernel(b, t, h, w):
+    """First-layer weight gradient with the BatchNorm / pool / LeakyReLU backward fused: the MFMA form (x and dy rounded to
+    bf16, positions as the K dimension) against the exact-f32 VALU kernel on the same inputs -- they differ by the operand
+    rounding only (2^-9 relative per element, averaged over b*t*h*w positions)."""
+    from maavss_amd import ops
+    x = torch.rand(b, t, h, w, generator=torch.Generator().manual_seed(1)).cuda()
+    wgt = rnd(16, 1, 3, 5, 5, seed=2, scale=0.1).cuda()
+    y, part = ops.conv3d_c1_fwd(x, wgt, want_stats=True)
+    mean, invstd = ops.bn_finalize(part, b * t * h * w)
+    gamma, beta = (1 + 0.3 * rnd(16, seed=3)).cuda(), (0.2 * rnd(16, seed=4)).cuda()
+    pool = 2
+    out, arg = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, ops.BN_LEAKY)
+    dout = rnd(*out.shape, seed=5).cuda()
+    dg, db = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+    coef = ops.bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, ops.BN_LEAKY, dgamma=dg, dbeta=db, beta=beta, coef_only=True)
+    dw32 = ops.conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, nchunk=5)
+    dw16 = ops.conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, nchunk=5, precise=ops.MODE_BF16)
+    rel = ((dw16 - dw32).norm() / dw32.norm()).item()
+    assert rel < 1e-2, rel
+    # accumulate form and a different chunking give the same sums
+    dw_acc = ops.conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, dw=dw16.clone(), beta=1, nchunk=3, precise=ops.MODE_BF16)
+    close(dw_acc, (2 * dw16).cpu(), 1e-4, 1e-4 * dw16.abs().max().item())
+
+
 def test_bn_pool_strided_output():
     """last visual stage writes the [B,16,T,S] block of the LSTM sequence buffer directly"""
     from maavss_amd import ops
