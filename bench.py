@@ -313,7 +313,7 @@ def main():
                 roofline["traffic"] = round(mb * 1e6)
                 roofline["traffic_unit"] = (f"bytes/launch (PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_hbm_traffic_latest.json, "
                                             f"tag {pmc.get('tag')}, same libmaavss_hip.so)")
-        breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:12]}
+        breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in by_time[:(None if args.verbose else 12)]}
         if args.verbose:
             shapes = {}
             for name, a, e0, e1 in timer.records:

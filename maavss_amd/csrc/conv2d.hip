@@ -1,7 +1,10 @@
 // K10 (convolution part): the STFT encoder's Conv2d(k=(3,9), stride (sh,sw) in {1,2}^2, pad (1,pw), bias=False)
 // layers (reference avse_model_final.py:98-102), forward / input gradient / weight gradient.
-// 2 -> 4 -> 8 -> 16 (-> 16) channels on at most [128 x 257] maps: a few MFLOP per clip, so these are plain
-// direct kernels (one thread per output element, inputs through L1/L2), HBM/latency-bound.
+// 2 -> 4 -> 8 -> 16 (-> 16) channels on at most [128 x 257] maps: a few MFLOP per clip, direct kernels, latency-bound.
+// Round 2: one thread per POSITION with all output (input) channels in registers -- every loaded value feeds C FMAs against
+// wave-uniform weights -- and a weight gradient whose blocks own a (ci, kh) row of 9 taps x all C_out; the first version
+// (one thread per output ELEMENT, one block per (co, ci) pair) re-read each input C times and cost 1.05 ms per step for
+// 0.2 GFLOP.
 // Input layout 0 = NCHW (the network input x_stft [B,2,T_a,F]) or 1 = NHWC; outputs are NHWC.
 // Weights stay in the reference layout [Co][Ci][3][9].
 #include "common.h"
@@ -34,6 +37,131 @@ __global__ __launch_bounds__(256) void conv2d_fwd_kernel(const float* __restrict
         }
       }
     y[i] = acc;
+  }
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_fwd_pos_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, C2Geom g) {
+  const int64_t npos = (int64_t)g.B * g.Ho * g.Wo;
+  for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < npos; pos += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(pos % g.Wo), oy = (int)((pos / g.Wo) % g.Ho), b = (int)(pos / ((int64_t)g.Wo * g.Ho));
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int ci = 0; ci < g.Ci; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy * g.sh + kh - 1;
+        const bool oky = iy >= 0 && iy < g.H;
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) {
+          const int ix = ox * g.sw + kw - g.pw;
+          float v = 0.f;
+          if (oky && ix >= 0 && ix < g.W) v = x[in_index(g, b, ci, iy, ix)];
+          const float* wp = w + ((int64_t)ci * 3 + kh) * 9 + kw;        // + co * Ci * 27: wave-uniform -> scalar loads
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[c] = fmaf(v, wp[(int64_t)c * g.Ci * 27], acc[c]);
+        }
+      }
+    float4* yp = reinterpret_cast<float4*>(y + pos * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) yp[c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  }
+}
+
+// one thread per INPUT position, all CI gradients in registers; dy rows read as float4
+template <int CI>
+__global__ __launch_bounds__(256) void conv2d_dgrad_pos_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               float* __restrict__ dx, C2Geom g) {
+  const int64_t npos = (int64_t)g.B * g.H * g.W;
+  for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < npos; pos += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), b = (int)(pos / ((int64_t)g.W * g.H));
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = iy + 1 - kh;
+      if (ty < 0 || ty % g.sh != 0) continue;
+      const int oy = ty / g.sh;
+      if (oy >= g.Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 9; ++kw) {
+        const int tx = ix + g.pw - kw;
+        if (tx < 0 || tx % g.sw != 0) continue;
+        const int ox = tx / g.sw;
+        if (ox >= g.Wo) continue;
+        const float4* dp = reinterpret_cast<const float4*>(dy + (((int64_t)b * g.Ho + oy) * g.Wo + ox) * g.Co);
+        for (int c4 = 0; c4 < g.Co / 4; ++c4) {
+          const float4 d = dp[c4];
+          const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* wp = w + ((int64_t)(c4 * 4 + e) * CI * 3 + kh) * 9 + kw;    // + ci * 27: wave-uniform
+#pragma unroll
+            for (int c = 0; c < CI; ++c) acc[c] = fmaf(dd[e], wp[c * 27], acc[c]);
+          }
+        }
+      }
+    }
+    float* xp = dx + pos * CI;
+    if constexpr (CI % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < CI; c += 4) *reinterpret_cast<float4*>(xp + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CI; ++c) xp[c] = acc[c];
+    }
+  }
+}
+
+// partials[chunk][co][ci][27]; block = ((ci, kh), chunk): 9 taps x all CO accumulators per thread, x row values loaded once
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_wgrad_row_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ partials, C2Geom g, int64_t pos_per_chunk) {
+  __shared__ float red[4][CO * 9];
+  const int ci = blockIdx.x / 3, kh = blockIdx.x % 3;
+  const int64_t npos = (int64_t)g.B * g.Ho * g.Wo;
+  const int64_t p0 = (int64_t)blockIdx.y * pos_per_chunk, p1 = min(npos, p0 + pos_per_chunk);
+  float acc[CO][9];
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
+  for (int64_t pos = p0 + threadIdx.x; pos < p1; pos += 256) {
+    const int ox = (int)(pos % g.Wo), oy = (int)((pos / g.Wo) % g.Ho), b = (int)(pos / ((int64_t)g.Wo * g.Ho));
+    const int iy = oy * g.sh + kh - 1;
+    if (iy < 0 || iy >= g.H) continue;
+    float xv[9];
+#pragma unroll
+    for (int kw = 0; kw < 9; ++kw) {
+      const int ix = ox * g.sw + kw - g.pw;
+      xv[kw] = (ix >= 0 && ix < g.W) ? x[in_index(g, b, ci, iy, ix)] : 0.f;
+    }
+    const float4* dp = reinterpret_cast<const float4*>(dy + pos * CO);
+#pragma unroll
+    for (int c4 = 0; c4 < CO / 4; ++c4) {
+      const float4 d = dp[c4];
+      const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) acc[c4 * 4 + e][kw] = fmaf(dd[e], xv[kw], acc[c4 * 4 + e][kw]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float s = wave_sum(acc[c][k]);
+      if (lane == 0) red[wv][c * 9 + k] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CO * 9; i += 256) {
+    const int co = i / 9, kw = i % 9;
+    partials[((int64_t)blockIdx.y * CO * g.Ci + (int64_t)co * g.Ci + ci) * 27 + kh * 9 + kw] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
 
@@ -125,8 +253,13 @@ extern "C" int maavss_conv2d_fwd(const float* x, const float* w, float* y, int B
   MAAVSS_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   C2Geom g;
   if (int rc = make_c2geom("conv2d_fwd", &g, B, Ci, H, W, Co, sh, sw, pw, in_layout)) return rc;
-  const int64_t total = (int64_t)B * g.Ho * g.Wo * Co;
-  hipLaunchKernelGGL(conv2d_fwd_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, g);
+  const int64_t total = (int64_t)B * g.Ho * g.Wo * Co, npos = (int64_t)B * g.Ho * g.Wo;
+  const dim3 pgrid(min((int64_t)8192, (npos + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (Co == 4) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<4>, pgrid, dim3(256), 0, st, x, w, y, g);
+  else if (Co == 8) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<8>, pgrid, dim3(256), 0, st, x, w, y, g);
+  else if (Co == 16) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<16>, pgrid, dim3(256), 0, st, x, w, y, g);
+  else hipLaunchKernelGGL(conv2d_fwd_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, st, x, w, y, g);
   MAAVSS_LAUNCH_CHECK("conv2d_fwd_kernel");
   return MAAVSS_OK;
 }
@@ -136,15 +269,22 @@ extern "C" int maavss_conv2d_dgrad(const float* dy, const float* w, float* dx, i
   MAAVSS_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
   C2Geom g;
   if (int rc = make_c2geom("conv2d_dgrad", &g, B, Ci, H, W, Co, sh, sw, pw, 1)) return rc;
-  const int64_t total = (int64_t)B * H * W * Ci;
-  hipLaunchKernelGGL(conv2d_dgrad_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, g);
+  const int64_t total = (int64_t)B * H * W * Ci, npos = (int64_t)B * H * W;
+  const dim3 pgrid(min((int64_t)8192, (npos + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (Co % 4 == 0 && Ci == 2) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<2>, pgrid, dim3(256), 0, st, dy, w, dx, g);
+  else if (Co % 4 == 0 && Ci == 4) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<4>, pgrid, dim3(256), 0, st, dy, w, dx, g);
+  else if (Co % 4 == 0 && Ci == 8) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<8>, pgrid, dim3(256), 0, st, dy, w, dx, g);
+  else if (Co % 4 == 0 && Ci == 16) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<16>, pgrid, dim3(256), 0, st, dy, w, dx, g);
+  else hipLaunchKernelGGL(conv2d_dgrad_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, st, dy, w, dx, g);
   MAAVSS_LAUNCH_CHECK("conv2d_dgrad_kernel");
   return MAAVSS_OK;
 }
 
 extern "C" int maavss_conv2d_wgrad_nchunk(int B, int Ho, int Wo, int Ci, int Co) {
   const int64_t npos = (int64_t)B * Ho * Wo;
-  int64_t n = 1024 / ((int64_t)Ci * Co);
+  // blocks = (ci, kh) rows x chunks for the row kernel (C_out in {4, 8, 16}), (co, ci) pairs x chunks otherwise
+  int64_t n = (Co == 4 || Co == 8 || Co == 16) ? 1536 / ((int64_t)Ci * 3) : 1024 / ((int64_t)Ci * Co);
   if (n < 1) n = 1;
   if (n > (npos + 1023) / 1024) n = (npos + 1023) / 1024;
   if (n < 1) n = 1;
@@ -160,7 +300,11 @@ extern "C" int maavss_conv2d_wgrad(const float* x, const float* dy, float* dw, f
   const int nchunk = maavss_conv2d_wgrad_nchunk(B, g.Ho, g.Wo, Ci, Co);
   const int64_t npos = (int64_t)B * g.Ho * g.Wo;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(Co * Ci, nchunk), dim3(256), 0, st, x, dy, ws, g, (npos + nchunk - 1) / nchunk);
+  const int64_t ppc = (npos + nchunk - 1) / nchunk;
+  if (Co == 4) hipLaunchKernelGGL(conv2d_wgrad_row_kernel<4>, dim3(Ci * 3, nchunk), dim3(256), 0, st, x, dy, ws, g, ppc);
+  else if (Co == 8) hipLaunchKernelGGL(conv2d_wgrad_row_kernel<8>, dim3(Ci * 3, nchunk), dim3(256), 0, st, x, dy, ws, g, ppc);
+  else if (Co == 16) hipLaunchKernelGGL(conv2d_wgrad_row_kernel<16>, dim3(Ci * 3, nchunk), dim3(256), 0, st, x, dy, ws, g, ppc);
+  else hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(Co * Ci, nchunk), dim3(256), 0, st, x, dy, ws, g, ppc);
   MAAVSS_LAUNCH_CHECK("conv2d_wgrad_kernel");
   const int n = Co * Ci * 27;
   hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, n, nchunk, beta);
