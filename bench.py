@@ -226,6 +226,8 @@ def main():
                 return 2.0 * a[8] * a[9] * a[10]                  # M, N, K
             if name == "maavss_vit_panel_gemm":
                 return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
+            if name == "maavss_vit_ws_gemm":
+                return 2.0 * a[8] * a[9] * 384                    # M, N, K = 384 (LayerNorm output flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
             if name == "maavss_vit_attn_fp8":
@@ -240,6 +242,9 @@ def main():
             if name == "maavss_vit_panel_gemm":
                 m, n, epi = a[11], a[12], a[13]
                 return m * 384 * (4.0 if a[0] else 2.0) + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n
+            if name == "maavss_vit_ws_gemm":
+                m, n, epi = a[8], a[9], a[10]                       # + the LayerNorm-ed 16-bit copy of the rows when asked for
+                return 2.0 * m * 384 + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n + (2.0 * m * 384 if a[13] else 0.0)
             if name == "maavss_vit_attn":
                 return a[2] * a[3] * (1152 + 384) * 2.0             # qkv in, attention output out, bf16
             if name == "maavss_vit_attn_fp8":
@@ -282,7 +287,7 @@ def main():
             if bytes_:
                 row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
             stages[name.replace("maavss_", "")] = row
-        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_gemm"):
+        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_gemm"):
             if nm in summ:
                 stage_row(nm, sum(flops_of(nm, a) for a in summ[nm]["args"]), sum(bytes_of(nm, a) for a in summ[nm]["args"]))
         if "maavss_stft_fwd" in summ:      # audio in (4 B/sample) + y and x out (2 planes x T_a x F x 4 B each)

@@ -259,6 +259,16 @@ int maavss_vit_layernorm(const float* x, const float* gamma, const float* beta, 
 int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* ln_gamma, const float* ln_beta,
                           float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M,
                           int N, int epilogue, int qscale_cols, float qscale, int dtype, void* stream);
+/* weight-stationary GEMM for the same K = 384 layers (attn.qkv, attn.proj, mlp.fc1 of dino's Block; call site
+ * video_attention.py:52): C = epilogue(A[M][384] (16-bit, dense rows) . W[N][384]^T), the weights held in registers, the
+ * activation rows streamed through LDS in 64-row panels.  epilogue 0 / 1 / 2 as in maavss_vit_gemm.  N % 384 == 0 (one
+ * workgroup per 384 columns; the N / 384 workgroups of a row range share one XCD's L2), ldc % 8 == 0, qscale_cols % 384 == 0.
+ * A and C must be ALLOCATED with a_rows, c_rows >= ceil(M/64)*64 rows (whole panels are read and stored; rows >= M hold
+ * don't-care values).  xn_out (epilogue 2 with N = 384 only, may be null): additionally LayerNorm(ln_gamma, ln_beta, ln_eps)
+ * of every updated row of C -> 16-bit [c_rows][384], so that the consumer GEMM needs no LayerNorm pass. */
+int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, const float* bias, void* C, int ldc,
+                       int64_t c_rows, int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream);
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
                     void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream);

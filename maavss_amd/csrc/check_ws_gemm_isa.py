@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Build-time check of vit_ws_gemm.hip's hand-counted panel fetch (run by the Makefile on the generated assembly).
+
+The kernel loads the next activation panel with inline-asm global_load_dwordx4 into four registers quads and waits for them
+with its own `s_waitcnt vmcnt(N)` one loop iteration later (the compiler cannot see that the registers are pending).  That is
+only correct if, between a fetch and the wait that follows it, the compiler never touches those registers: no spill, no copy,
+no reuse.  This script proves it on the emitted ISA: every instruction whose nearest preceding asm block (in layout order,
+which is also execution order inside the single-loop kernel) is a FETCH must not mention a fetched register, and no kernel may
+use scratch.  Exit status 1 with the offending line otherwise."""
+import re
+import sys
+
+
+def regs_of(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(x) for x in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+def main(path):
+    src = open(path).read()
+    bad = 0
+    funcs = re.findall(r"^(_Z\d+vit_ws_gemm_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", src, re.S | re.M)
+    if not funcs:
+        print("check_ws_gemm_isa: no vit_ws_gemm_kernel in", path)
+        return 1
+    for name, body in funcs:
+        lines = body.split("\n")
+        if any("scratch_" in ln for ln in lines):
+            print(f"{name}: uses scratch memory (register spills): the fetch registers may be spilled while their loads are in flight")
+            bad += 1
+        state, pending, in_asm, block = "idle", set(), False, []
+        n_fetch = n_wait = 0
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm, block = True, []
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                txt = "\n".join(block)
+                if "global_load_dwordx4" in txt:
+                    state, n_fetch = "pending", n_fetch + 1
+                    pending = set()
+                    for b in block:
+                        m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", b.strip())
+                        if m:
+                            pending.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                elif "s_waitcnt vmcnt" in txt and state == "pending":
+                    state, n_wait = "idle", n_wait + 1
+                continue
+            if in_asm:
+                block.append(t)
+                continue
+            if state == "pending" and t and not t.startswith(";") and not t.startswith("."):
+                code = t.split(";")[0]
+                hit = regs_of(code) & pending
+                if hit:
+                    print(f"{name}: `{code.strip()}` touches v{sorted(hit)} while the panel fetch into them is in flight")
+                    bad += 1
+        if n_fetch != 2 or n_wait != 2:
+            print(f"{name}: expected the two fetch sites (prologue, loop) and their waits, found {n_fetch} / {n_wait}")
+            bad += 1
+    print(f"check_ws_gemm_isa: {len(funcs)} kernels, {bad} problem(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

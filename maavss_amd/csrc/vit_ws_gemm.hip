@@ -1,0 +1,324 @@
+// K2/K3, weight-stationary form: the K = 384 dense layers of the ViT blocks (attn.qkv, attn.proj, mlp.fc1 of dino's Block,
+// reached from the reference through video_attention.py:52) with the WEIGHTS held in registers and the activations streamed.
+//
+// Why: the panel-stationary kernel (vit_panel_gemm.hip) keeps a [128 x 384] activation panel in LDS and streams weight tiles
+// through an LDS ring; per 32-deep step its eight MFMA waves read 48 KiB of fragments for 258 cycles of MFMA (75 % of the
+// LDS bandwidth), the panel build and the output stores run with the matrix pipe idle, and the ring takes the other 64 KiB.
+// Here
+//   * a workgroup (12 waves, 3 per SIMD) owns 384 output columns: wave w keeps W[n0 + 32 w .. +32][0 .. 384) as 24
+//     A-operand fragments of v_mfma_f32_32x32x16 (96 registers) for its whole life -- no weight traffic after the first
+//     25 KiB per wave;
+//   * the 16-bit activation rows stream through LDS in [64 x 384] panels (48 KiB, two buffers): each wave fetches 4 KiB of
+//     the panel after next into registers (four 16-byte loads, in flight during a whole panel of MFMAs) and writes them to
+//     the free buffer after the next barrier.  (LDS-DMA would save the 16 registers, but hipcc waits vmcnt(0) before every
+//     LDS read of a wave that has a global_load_lds in flight -- it cannot tell the destinations apart.)  Every wave reads
+//     the whole panel: one 16-byte fragment read per MFMA = 50 % of the LDS read bandwidth at full matrix rate;
+//   * N > 384 (qkv 1152, fc1 1536) is covered by ns = N / 384 workgroups that walk the SAME rows on CUs of one XCD (the
+//     panel is fetched from HBM once and served to the others by that XCD's L2);
+//   * each wave stores its own [32 x 32] outputs straight from the accumulators (the MFMA row permutation below gives a lane
+//     8 consecutive columns): with three waves per SIMD one wave's epilogue runs under the other two's MFMAs;
+//   * one workgroup barrier per panel.
+// Epilogues: 0 +bias, q-scale -> 16-bit | 1 +bias, GELU -> 16-bit | 2 +bias +residual -> f32 in place, and optionally the
+// NEXT LayerNorm of the updated rows -> 16-bit (ns = 1: the workgroup holds whole rows), so that the consumer GEMM needs no
+// LayerNorm pass.
+#include "mma.h"
+#include "vit_epilogue.h"
+
+#define WS_K 384
+#define WS_BM 64
+#define WS_WAVES 12
+#define WS_THREADS (WS_WAVES * 64)
+#define WS_SLICE (WS_WAVES * 32)
+#define WS_BUFS 2
+#define WS_PANEL_BYTES (WS_BM * WS_K * 2)
+
+struct WsArgs {
+  const bf16_t* A;       // 16-bit [ceil(M/64)*64][384]
+  const bf16_t* W;       // 16-bit [N][384]
+  const float* bias;     // [N]
+  void* C;               // 16-bit [c_rows][ldc] (epi 0, 1) or f32 [c_rows][ldc] (epi 2, read-modify-write)
+  bf16_t* XN;            // epi 2, optional: LayerNorm(C row) -> 16-bit [c_rows][384]
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  int M, N, ldc;
+  int qscale_cols;
+  float qscale;
+  int ns;                // column slices of 384
+  int groups_per_xcd;    // (CUs per XCD) / ns
+  int panels;            // ceil(M / 64)
+};
+
+template <int EPI, bool LN_OUT, int MODE>
+__global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panels_lds = smem;                                                       // 2 x 48 KiB
+  float* bias_lds = reinterpret_cast<float*>(smem + WS_BUFS * WS_PANEL_BYTES);   // [384] (+ [384] gamma, [384] beta, stats)
+  float* gam_lds = bias_lds + WS_SLICE;
+  float* bet_lds = gam_lds + WS_SLICE;
+  float2* stat_lds = reinterpret_cast<float2*>(bet_lds + WS_SLICE);              // [64 rows][12 waves] (mean, M2) of 32 columns
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, half = lane >> 5;
+  // workgroup -> (XCD, slot): dispatch is round-robin over the 8 XCDs, so blockIdx & 7 is the XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  if (slot >= g.groups_per_xcd * g.ns) return;
+  const int slice = slot % g.ns, group = xcd * g.groups_per_xcd + slot / g.ns, ngroups = 8 * g.groups_per_xcd;
+  const int p0 = (int)((int64_t)g.panels * group / ngroups), p1 = (int)((int64_t)g.panels * (group + 1) / ngroups);
+  if (p0 >= p1) return;
+  const int n0 = slice * WS_SLICE + wv * 32;
+#ifdef MAAVSS_WS_ABL
+  constexpr int abl = MAAVSS_WS_ABL;   // measurement builds only (scripts/gemm_ablate.sh): bit mask of loop parts to skip
+#else
+  constexpr int abl = 0;
+#endif
+
+  // ---- panel stream.  A panel is 48 KiB of contiguous memory = 3072 chunks of 16 B; chunk q = 64 (4 wv + i) + lane is row
+  // q / 48, chunk c = q % 48 of it, and goes to LDS byte r * 768 + ((c ^ (r & 15)) << 4): a fragment read (32 rows x 2
+  // chunks per wave-instruction) then touches every bank group once per 16-lane service group.
+  // The four loads are inline asm and their completion is waited for by hand (WS_WAIT_FETCH): vmcnt retires in issue order
+  // over loads AND stores, and hipcc, merging the loop-carried state, waits vmcnt(0..3) before the LDS writes -- i.e. for the
+  // acknowledgement of the output stores issued just before -- and flushes vmcnt(0) in front of the inner loop.  Counted by
+  // hand, the wait lets exactly the `S` vector-memory operations of one panel epilogue (all younger than the fetch) fly.
+  // The compiler does not know that the four registers are pending between fetch and wait: both sit in the SAME loop
+  // iteration (no loop-carried copy), the wait has no register operands (no tied-operand copy), and the build runs
+  // check_ws_gemm_isa.py over the emitted ISA, which fails if any instruction touches them in between or a kernel spills.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 stg0, stg1, stg2, stg3;
+#define WS_FETCH(p)                                                                                               \
+  {                                                                                                               \
+    const char* src_ = reinterpret_cast<const char*>(g.A + (int64_t)(p) * (WS_BM * WS_K)) + (wv * 256 + lane) * 16; \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"            \
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"      \
+                 : "=&v"(stg0), "=&v"(stg1), "=&v"(stg2), "=&v"(stg3) : "v"(src_) : "memory");                     \
+  }
+#define WS_WAIT_FETCH(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory");
+#define WS_DEPOSIT_ONE(i, v)                                                                                      \
+  {                                                                                                               \
+    const int q_ = (wv * 4 + i) * 64 + ln_, r_ = q_ / 48, c_ = q_ - r_ * 48;                                      \
+    *reinterpret_cast<u32x4*>(dst_ + r_ * (WS_K * 2) + ((c_ ^ (r_ & 15)) << 4)) = v;                             \
+  }
+#define WS_DEPOSIT(buf)                                                                                           \
+  {                                                                                                               \
+    int ln_ = lane;                                                                                               \
+    asm volatile("" : "+v"(ln_)); /* keeps the four offsets out of the loop-invariant (= permanently live) registers */ \
+    char* dst_ = panels_lds + (buf) * WS_PANEL_BYTES;                                                             \
+    WS_DEPOSIT_ONE(0, stg0) WS_DEPOSIT_ONE(1, stg1) WS_DEPOSIT_ONE(2, stg2) WS_DEPOSIT_ONE(3, stg3)               \
+  }
+  // residual epilogues (HBM-bound, and short of registers once the LayerNorm output is on): the panel travels in two halves of
+  // 32 rows, each fetched at the start and written at the end of the half-panel step it overlaps -- 8 staging registers
+#define WS_FETCH_HALF(p, part)                                                                                    \
+  {                                                                                                               \
+    const char* src_ = reinterpret_cast<const char*>(g.A + (int64_t)(p) * (WS_BM * WS_K)) + ((part) * 1536 + wv * 128 + lane) * 16; \
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024"                 \
+                 : "=&v"(stg0), "=&v"(stg1) : "v"(src_) : "memory");                                               \
+  }
+#define WS_DEPOSIT_HALF_ONE(part, i, v)                                                                           \
+  {                                                                                                               \
+    const int q_ = (part) * 1536 + (wv * 2 + i) * 64 + ln_, r_ = q_ / 48, c_ = q_ - r_ * 48;                      \
+    *reinterpret_cast<u32x4*>(dst_ + r_ * (WS_K * 2) + ((c_ ^ (r_ & 15)) << 4)) = v;                              \
+  }
+#define WS_DEPOSIT_HALF(buf, part)                                                                                \
+  {                                                                                                               \
+    int ln_ = lane;                                                                                               \
+    asm volatile("" : "+v"(ln_));                                                                                 \
+    char* dst_ = panels_lds + (buf) * WS_PANEL_BYTES;                                                             \
+    WS_DEPOSIT_HALF_ONE(part, 0, stg0) WS_DEPOSIT_HALF_ONE(part, 1, stg1)                                         \
+  }
+  constexpr bool SPLIT = EPI == 2;
+  WS_FETCH(p0)
+
+  // ---- stationary weights.  MFMA row i = 8 q + 4 h + r of the A operand is fed with weight row n0 + pi(i),
+  // pi(i) = 16 (q >> 1) + 8 h + 4 (q & 1) + r: the accumulator registers (q, r) of a lane (column = activation row, h = lane
+  // half) are then the 8 consecutive output columns 16 (q >> 1) + 8 h + (0..7) for q = (0,1) and (2,3).
+  bf16x8 w[24];
+  {
+    const int q = r32 >> 3, h = (r32 >> 2) & 1, r = r32 & 3;
+    const bf16_t* wp = g.W + (int64_t)(n0 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + r) * WS_K + 8 * half;
+#pragma unroll
+    for (int kb = 0; kb < 24; ++kb) w[kb] = *reinterpret_cast<const bf16x8*>(wp + kb * 16);
+  }
+  if (tid < WS_SLICE) {
+    bias_lds[tid] = g.bias[slice * WS_SLICE + tid];
+    if constexpr (LN_OUT) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
+  }
+  WS_WAIT_FETCH(0)
+  WS_DEPOSIT(0)
+  // fragment read address: activation row r32 (+ 32 h2), chunk 2 kb + half, kb = 8 a + b:
+  //   ((2 b + half) ^ (r32 & 15)) << 4  =  (((b << 5) ^ ((r32 & 14) << 4))) + ((half ^ (r32 & 1)) << 4)
+  const int frag_r = r32 * (WS_K * 2) + ((half ^ (r32 & 1)) << 4), frag_x = (r32 & 14) << 4;
+  const float scale = (EPI == 0 && slice * WS_SLICE < g.qscale_cols) ? g.qscale : 1.f;   // qscale_cols is a multiple of 384
+
+  constexpr int S = EPI == 2 ? (LN_OUT ? 20 : 16) : 4;   // vector-memory operations of one panel epilogue (loads + stores)
+  int it = 0;
+  for (int p = p0; p < p1; ++p, ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(abl & 16)) __builtin_amdgcn_s_barrier();      // panel p is in LDS for everybody; everybody is done reading panel p-1
+    const bool more = p + 1 < p1 && !((abl & 2) && it > 0);
+    if constexpr (!SPLIT) { if (more) WS_FETCH(p + 1) }   // in flight during this panel's MFMAs, written to the other buffer at the end
+    const int m0 = p * WS_BM;
+#pragma unroll 1
+    for (int h2 = 0; h2 < 2; ++h2) {
+      if constexpr (SPLIT) { if (more) WS_FETCH_HALF(p + 1, h2) }
+      const char* pb = panels_lds + buf * WS_PANEL_BYTES + h2 * (32 * WS_K * 2) + frag_r;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bq = *reinterpret_cast<const float4*>(bias_lds + wv * 32 + 16 * (q >> 1) + 8 * half + 4 * (q & 1));
+        acc[4 * q + 0] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+      }
+      auto rd = [&](int kb) __attribute__((always_inline)) {
+        int fx = frag_x;
+        asm volatile("" : "+v"(fx));   // recomputed per read (one v_xad): eight precomputed addresses would stay live for the whole kernel
+        return *reinterpret_cast<const bf16x8*>(pb + (((kb & 7) << 5) ^ fx) + (kb >> 3) * 256);
+      };
+      // fragment reads kept in flight ahead of the MFMA that consumes them (the residual epilogues are HBM-bound and short of
+      // registers: one)
+      constexpr int WS_DEPTH = EPI == 2 ? 1 : 3;
+      bf16x8 f[WS_DEPTH + 1];
+#pragma unroll
+      for (int kb = 0; kb < WS_DEPTH; ++kb) f[kb] = rd(kb);
+#pragma unroll
+      for (int kb = 0; kb < 24; ++kb) {
+        if (kb + WS_DEPTH < 24 && !(abl & 8)) f[(kb + WS_DEPTH) % (WS_DEPTH + 1)] = rd(kb + WS_DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 4)) Mma32<MODE>::mma(acc, w[kb], f[kb % (WS_DEPTH + 1)]);
+        else if (kb == 23) acc[0] += (float)(f[0][0] + f[1][1] + f[2][2] + f[3][3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      // ---- epilogue: lane (r32, half) holds, of row m0 + 32 h2 + r32, the columns n0 + 16 qp + 8 half + (0..7), qp = 0, 1
+      const int64_t row = m0 + 32 * h2 + r32;
+      bool skip_epi = false;
+      if constexpr ((abl & 1) != 0) skip_epi = acc[3] != 1234.5f;
+      if (!skip_epi) {
+      if constexpr (EPI != 2) {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + row * g.ldc + n0 + 8 * half;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          v2f v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v2f{acc[8 * qp + 2 * e], acc[8 * qp + 2 * e + 1]};
+          if constexpr (EPI == 1) {
+            pg_gelu4(v[0], v[1]);
+            pg_gelu4(v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * scale;
+          }
+          *reinterpret_cast<uint4*>(cp + 16 * qp) = make_uint4(pack2<MODE>(v[0].x, v[0].y), pack2<MODE>(v[1].x, v[1].y),
+                                                                 pack2<MODE>(v[2].x, v[2].y), pack2<MODE>(v[3].x, v[3].y));
+        }
+      } else {
+        float* cp = reinterpret_cast<float*>(g.C) + row * g.ldc + n0 + 8 * half;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {     // two 16-byte pieces at a time: the residual epilogues are short of registers
+          const float4 x0 = *reinterpret_cast<const float4*>(cp + 16 * qp), x1 = *reinterpret_cast<const float4*>(cp + 16 * qp + 4);
+          acc[8 * qp + 0] += x0.x; acc[8 * qp + 1] += x0.y; acc[8 * qp + 2] += x0.z; acc[8 * qp + 3] += x0.w;
+          acc[8 * qp + 4] += x1.x; acc[8 * qp + 5] += x1.y; acc[8 * qp + 6] += x1.z; acc[8 * qp + 7] += x1.w;
+          *reinterpret_cast<float4*>(cp + 16 * qp) = make_float4(acc[8 * qp], acc[8 * qp + 1], acc[8 * qp + 2], acc[8 * qp + 3]);
+          *reinterpret_cast<float4*>(cp + 16 * qp + 4) = make_float4(acc[8 * qp + 4], acc[8 * qp + 5], acc[8 * qp + 6], acc[8 * qp + 7]);
+        }
+        if constexpr (LN_OUT) {
+          // LayerNorm of the updated rows: per wave (mean, M2) of its 32 columns of a row (two passes over registers, the two
+          // lane halves combined by a lane swap), the 12 partials of a row merged with the parallel-variance formula.
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += acc[e];
+          float sa, sb;
+          lane_swap32(s, sa, sb);
+          const float mu = (sa + sb) * (1.f / 32.f);
+          float m2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const float d = acc[e] - mu; m2 += d * d; }
+          lane_swap32(m2, sa, sb);
+          float2* sp = stat_lds + (32 * h2 + r32) * WS_WAVES;
+          if (half == 0) sp[wv] = make_float2(mu, sa + sb);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          float mean = 0.f;
+#pragma unroll 4
+          for (int k = 0; k < WS_WAVES; ++k) mean += sp[k].x;
+          mean *= 1.f / WS_WAVES;
+          float tot = 0.f;
+#pragma unroll 4
+          for (int k = 0; k < WS_WAVES; ++k) { const float2 st = sp[k]; const float d = st.x - mean; tot += st.y + 32.f * d * d; }
+          const float rstd = rsqrtf(tot * (1.f / WS_K) + g.ln_eps);
+          bf16_t* xp = g.XN + row * WS_K + n0 + 8 * half;
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const int nl = wv * 32 + 16 * qp + 8 * half;
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float4 gg = *reinterpret_cast<const float4*>(gam_lds + nl + 4 * e), bb = *reinterpret_cast<const float4*>(bet_lds + nl + 4 * e);
+              o[2 * e] = pack2<MODE>((acc[8 * qp + 4 * e + 0] - mean) * rstd * gg.x + bb.x, (acc[8 * qp + 4 * e + 1] - mean) * rstd * gg.y + bb.y);
+              o[2 * e + 1] = pack2<MODE>((acc[8 * qp + 4 * e + 2] - mean) * rstd * gg.z + bb.z, (acc[8 * qp + 4 * e + 3] - mean) * rstd * gg.w + bb.w);
+            }
+            *reinterpret_cast<uint4*>(xp + 16 * qp) = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      }
+      }   // skip_epi (measurement builds)
+      if constexpr (SPLIT) {
+        if (more) {
+          WS_WAIT_FETCH(S / 2)         // younger than the fetch: this half-panel's S / 2 epilogue operations
+          WS_DEPOSIT_HALF(buf ^ 1, h2)
+        }
+      }
+    }
+    if constexpr (!SPLIT) {
+      if (more) {
+        WS_WAIT_FETCH(S)               // younger than the fetch: exactly this panel's S epilogue operations
+        WS_DEPOSIT(buf ^ 1)            // the buffer panel p-1 left at this iteration's barrier
+      }
+    }
+  }
+}
+
+extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, const float* bias, void* C, int ldc, int64_t c_rows,
+                                  int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
+                                  const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream) {
+  MAAVSS_CHECK_ARG(A && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm: bad arguments");
+  MAAVSS_CHECK_ARG(N % WS_SLICE == 0 && N >= WS_SLICE, "vit_ws_gemm: N must be a multiple of 384 (got %d)", N);
+  MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "vit_ws_gemm: unknown epilogue");
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm: dtype must be 0 (bf16) or 2 (f16)");
+  MAAVSS_CHECK_ARG(lda == WS_K, "vit_ws_gemm: A must be dense [rows][384] (lda = %d)", lda);
+  MAAVSS_CHECK_ARG(a_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm: A needs ceil(M/64)*64 = %ld allocated rows (got %ld): whole panels are read",
+                   (long)cdiv(M, WS_BM) * WS_BM, (long)a_rows);
+  MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm: ldc must be a multiple of 8, qscale_cols a multiple of 384");
+  MAAVSS_CHECK_ARG(c_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm: C needs ceil(M/64)*64 = %ld allocated rows (got %ld): stores are unguarded",
+                   (long)cdiv(M, WS_BM) * WS_BM, (long)c_rows);
+  MAAVSS_CHECK_ARG(!xn_out || (epilogue == 2 && N == WS_SLICE && ln_gamma && ln_beta),
+                   "vit_ws_gemm: the LayerNorm output needs epilogue 2, N = 384 and the LayerNorm parameters");
+  static int n_cu_dev[64] = {0};
+  int dev = 0;
+  MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "vit_ws_gemm: cannot query the device");
+  if (!n_cu_dev[dev]) {
+    hipDeviceProp_t prop;
+    MAAVSS_CHECK_ARG(hipGetDeviceProperties(&prop, dev) == hipSuccess, "vit_ws_gemm: cannot query the device");
+    n_cu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int cu_per_xcd = n_cu_dev[dev] / 8 > 0 ? n_cu_dev[dev] / 8 : 1;
+  WsArgs g;
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.XN = (bf16_t*)xn_out;
+  g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
+  g.M = (int)M; g.N = N; g.ldc = ldc; g.qscale_cols = qscale_cols; g.qscale = qscale;
+  g.ns = N / WS_SLICE;
+  MAAVSS_CHECK_ARG(g.ns <= cu_per_xcd, "vit_ws_gemm: N too large for one XCD's CUs");
+  g.groups_per_xcd = cu_per_xcd / g.ns;
+  g.panels = cdiv(M, WS_BM);
+  const size_t smem = WS_BUFS * WS_PANEL_BYTES + 3 * WS_SLICE * sizeof(float) + WS_BM * WS_WAVES * sizeof(float2);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(8 * cu_per_xcd), block(WS_THREADS);
+#define WS_LAUNCH3(E, L, D)                                                                                           \
+  {                                                                                                                   \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_ws_gemm_kernel<E, L, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                      \
+  }
+#define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
+  if (epilogue == 0) WS_LAUNCH(0, false) else if (epilogue == 1) WS_LAUNCH(1, false) else if (xn_out) WS_LAUNCH(2, true) else WS_LAUNCH(2, false)
+#undef WS_LAUNCH3
+#undef WS_LAUNCH
+  MAAVSS_LAUNCH_CHECK("vit_ws_gemm_kernel");
+  return MAAVSS_OK;
+}

@@ -122,6 +122,8 @@ class VideoAttention:
         self.device = torch.device(device)
         self.frames_per_launch = frames_per_launch
         self.fused_panel_gemm = os.environ.get("MAAVSS_VIT_PANEL_GEMM", "1") != "0"   # LN+GEMM panel kernel for K=384
+        # K = 384 layers on the weight-stationary kernel (maavss_vit_ws_gemm): norm1 as its own pass, norm2 written by proj
+        self.ws_gemm = os.environ.get("MAAVSS_VIT_WS_GEMM", "1") != "0"
         self.model = self.__load_model(path_to_weights)
         self._dev = None          # device-side weight images, built lazily
         self._tables = {}
@@ -189,9 +191,9 @@ class VideoAttention:
         rpad = (rows + 127) // 128 * 128      # the panel GEMM stores whole 128-row panels (include/maavss.h)
         a = torch.empty(rows, 192, device=dev, dtype=tdt)
         x = torch.empty(rpad, DIM, device=dev, dtype=torch.float32)
-        xn = torch.empty(rows, DIM, device=dev, dtype=tdt) if not self.fused_panel_gemm else None
+        xn = torch.empty(rpad, DIM, device=dev, dtype=tdt) if (self.ws_gemm or not self.fused_panel_gemm) else None
         qkv = torch.empty(rpad, 3 * DIM, device=dev, dtype=tdt)
-        att_o = torch.empty(rows, DIM, device=dev, dtype=tdt)
+        att_o = torch.empty(rpad, DIM, device=dev, dtype=tdt)
         hid = torch.empty(rpad, MLP, device=dev, dtype=tdt)
         ws8 = None
         if self.attn_fp8:
@@ -205,7 +207,12 @@ class VideoAttention:
             # the last block only feeds the CLS-row attention (get_last_selfattention): q and k, not v -- the weight rows
             # are [q; k; v], so N = 2 DIM computes exactly those two thirds into the same [rows, 3 DIM] buffer
             nqkv = 2 * DIM if i == DEPTH - 1 else 3 * DIM
-            if self.fused_panel_gemm:
+            if self.ws_gemm:
+                # norm1 (own pass), then qkv with the weights stationary in registers
+                call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, dt, st)
+                call("maavss_vit_ws_gemm", ptr(xn), DIM, rpad, ptr(b["qkv_w"]), ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv,
+                     EPI_BF16_BIAS, DIM, qs, None, None, None, LN_EPS, dt, st)
+            elif self.fused_panel_gemm:
                 # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
                      ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv, EPI_BF16_BIAS, DIM, qs, dt, st)
@@ -219,7 +226,13 @@ class VideoAttention:
                 call("maavss_vit_attn_fp8", ptr(qkv), ptr(att_o), ptr(ws8), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
             else:
                 call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
-            if self.fused_panel_gemm:
+            if self.ws_gemm:
+                # proj adds into the residual stream and writes norm2 of the updated rows; fc1 reads that
+                call("maavss_vit_ws_gemm", ptr(att_o), DIM, rpad, ptr(b["proj_w"]), ptr(b["proj_b"]), ptr(x), DIM, rpad, rows, DIM,
+                     EPI_F32_BIAS_RESID, 0, 1.0, ptr(xn), ptr(b["n2w"]), ptr(b["n2b"]), LN_EPS, dt, st)
+                call("maavss_vit_ws_gemm", ptr(xn), DIM, rpad, ptr(b["fc1_w"]), ptr(b["fc1_b"]), ptr(hid), MLP, rpad, rows, MLP,
+                     EPI_BF16_BIAS_GELU, 0, 1.0, None, None, None, LN_EPS, dt, st)
+            elif self.fused_panel_gemm:
                 call("maavss_vit_panel_gemm", None, ptr(att_o), DIM, None, None, LN_EPS, ptr(b["proj_w"]), ptr(b["proj_b"]),
                      ptr(x), DIM, rpad, rows, DIM, EPI_F32_BIAS_RESID, 0, 1.0, dt, st)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n2w"]), ptr(b["n2b"]), LN_EPS, ptr(b["fc1_w"]),

@@ -119,7 +119,7 @@ def test_end_to_end_frames_to_mask_with_the_vit_in_the_loop(act):
           f"mask-MSE {mse:.3e}; |dloss| {abs(loss.item() - loss_ref.item()):.3e} (loss {loss_ref.item():.5f})")
     if act == "f16":
         assert mse <= 1e-5, mse                                   # BASELINE.json: mask MSE within 1e-5 of the reference
-        assert abs(loss.item() - loss_ref.item()) <= 2e-5
+        assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-5      # same bound as the benched-shape test above
     else:
         assert mse <= 1e-3, mse
         assert abs(loss.item() - loss_ref.item()) <= 5e-4

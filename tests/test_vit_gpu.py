@@ -124,6 +124,50 @@ def test_vit_panel_gemm_fused_layernorm(m, n, dt):
               m - 1 if m % 128 == 0 else m, m, n, 2, 0, 1.0, dt, _st())
 
 
+@pytest.mark.parametrize("dt", [0, 2])
+@pytest.mark.parametrize("m,n", [(1000, 1152), (785 * 2 + 3, 1536), (130, 384), (64 * 300 + 1, 768), (16 * 1025, 384), (64 * 300 + 1, 384),
+                                 (64 * 300 + 1, 1536)])
+def test_vit_ws_gemm(m, n, dt):
+    """weight-stationary K = 384 GEMM against torch on the same 16-bit operands, f32 accumulate: the three epilogues,
+    and the LayerNorm-of-the-updated-row output of epilogue 2.  Shapes with none, one and several 64-row panels per
+    workgroup (256 / 128 / 80 / 64 row groups for N = 384 / 768 / 1152 / 1536), ragged last panel."""
+    k = 384
+    a = rd(rnd(m, k, seed=6), dt)
+    w, bias = rd(rnd(n, k, seed=4, scale=k ** -0.5), dt), rnd(n, seed=5, scale=0.1)
+    z = a.float() @ w.float().t() + bias
+    mp = (m + 63) // 64 * 64                          # inputs and outputs are allocated in whole 64-row panels
+    ac = torch.full((mp, k), float("nan"), dtype=DT[dt], device="cuda")      # the padding rows hold anything
+    ac[:m] = a.cuda()
+    wc, biasc = w.cuda(), bias.cuda()
+    c = torch.empty(mp, n, dtype=DT[dt], device="cuda")
+    _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), c.data_ptr(), n, mp, m, n, 0, 384, 0.125,
+          None, None, None, 1e-6, dt, _st())
+    want = z.clone()
+    want[:, :384] *= 0.125
+    np.testing.assert_allclose(c[:m].float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), c.data_ptr(), n, mp, m, n, 1, 0, 1.0,
+          None, None, None, 1e-6, dt, _st())
+    np.testing.assert_allclose(c[:m].float().cpu().numpy(), F.gelu(z).numpy(), rtol=1.5e-2, atol=1.5e-2)
+    res = rnd(m, n, seed=7)
+    rc = torch.zeros(mp, n, device="cuda")
+    rc[:m] = res.cuda()
+    _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, mp, m, n, 2, 0, 1.0,
+          None, None, None, 1e-6, dt, _st())
+    np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=3e-4)
+    if n == 384:
+        gam, bet = 1 + 0.1 * rnd(k, seed=2), 0.1 * rnd(k, seed=3)
+        gc, bc = gam.cuda(), bet.cuda()
+        rc[:m] = res.cuda()
+        xn = torch.empty(mp, k, dtype=DT[dt], device="cuda")
+        _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, mp, m, n, 2, 0, 1.0,
+              xn.data_ptr(), gc.data_ptr(), bc.data_ptr(), 1e-6, dt, _st())
+        np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=3e-4)
+        np.testing.assert_allclose(xn[:m].float().cpu().numpy(), F.layer_norm(res + z, (k,), gam, bet, 1e-6).numpy(), rtol=8e-3, atol=8e-3)
+    with pytest.raises(Exception):                     # unpadded buffers are refused
+        _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, m - 1 if m % 64 == 0 else m,
+              m, n, 2, 0, 1.0, None, None, None, 1e-6, dt, _st())
+
+
 def test_vit_layernorm_and_patchify():
     rows = 1003
     x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
