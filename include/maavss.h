@@ -269,6 +269,17 @@ int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* l
 int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, const float* bias, void* C, int ldc,
                        int64_t c_rows, int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream);
+/* norm1 -> attn.qkv without a LayerNorm pass: X f32 [x_rows][384] is normalised on the way into LDS (epilogue 0: +bias,
+ * q-scale -> 16-bit).  row_stats [M][3][2] = (mean, sum of squared deviations) of the three 128-column thirds of every row of X,
+ * as left by maavss_vit_gemm_stats when it wrote X. */
+int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
+                          float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N,
+                          int qscale_cols, float qscale, int dtype, void* stream);
+/* maavss_vit_gemm with the f32 epilogues (2, 3) additionally writing, for every row and every 128-column tile, (mean, sum of
+ * squared deviations from that mean) of the values it stored: row_stats [M][N / 128][2] (null = maavss_vit_gemm). */
+int maavss_vit_gemm_stats(const void* A, int lda, const void* W, const float* bias, const float* table, int period, void* C,
+                          int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale, float* row_stats,
+                          int dtype, void* stream);
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
                     void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream);

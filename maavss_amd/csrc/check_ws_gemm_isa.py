@@ -41,11 +41,11 @@ def main(path):
             if t.startswith(";;#ASMEND"):
                 in_asm = False
                 txt = "\n".join(block)
-                if "global_load_dwordx4" in txt:
+                if "global_load_dwordx" in txt:
                     state, n_fetch = "pending", n_fetch + 1
                     pending = set()
                     for b in block:
-                        m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", b.strip())
+                        m = re.match(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", b.strip())
                         if m:
                             pending.update(range(int(m.group(1)), int(m.group(2)) + 1))
                 elif "s_waitcnt vmcnt" in txt and state == "pending":
@@ -60,8 +60,9 @@ def main(path):
                 if hit:
                     print(f"{name}: `{code.strip()}` touches v{sorted(hit)} while the panel fetch into them is in flight")
                     bad += 1
-        if n_fetch != 2 or n_wait != 2:
-            print(f"{name}: expected the two fetch sites (prologue, loop) and their waits, found {n_fetch} / {n_wait}")
+        if n_fetch < 2 or n_wait < 2 or state != "idle":
+            print(f"{name}: expected fetch sites in the prologue and in the loop, each followed by its wait: found {n_fetch} fetches, "
+                  f"{n_wait} waits, final state {state}")
             bad += 1
     print(f"check_ws_gemm_isa: {len(funcs)} kernels, {bad} problem(s)")
     return 1 if bad else 0

@@ -56,6 +56,7 @@ struct VGemmArgs {
   int qscale_cols;        // EPI 0: columns < qscale_cols are multiplied by qscale after the bias
   float qscale;
   int tiles_n, tiles_m;
+  float* row_stats;       // f32 epilogues, optional: [M][tiles_n][2] = (mean, sum of squared deviations) of each row's 128 tile columns
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
@@ -313,6 +314,16 @@ __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
             else add = res;
             const float4 o4 = make_float4(a.x + add.x, a.y + add.y, a.z + add.z, a.w + add.w);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o4), crsrc, voff + (pass * 4 + it) * cstep, 0, 0);
+            if (g.row_stats != nullptr) {
+              // LayerNorm statistics of the stored row over this tile's 128 columns (32 consecutive lanes = one row): the
+              // consumer (vit_ws_gemm with LayerNorm on the way in) merges the N / 128 partials of a row
+              const float mt = half_wave_sum((o4.x + o4.y) + (o4.z + o4.w)) * (1.f / VG_BN);
+              const float dx = o4.x - mt, dy = o4.y - mt, dz = o4.z - mt, dw = o4.w - mt;
+              const float m2 = half_wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw));
+              const int m = m0 + pass * 64 + row;
+              if ((tid & 31) == 0 && m < g.M)
+                *reinterpret_cast<float2*>(g.row_stats + ((int64_t)m * g.tiles_n + n0 / VG_BN) * 2) = make_float2(mt, m2);
+            }
           }
           if (pass < 2) {
 #pragma unroll
@@ -333,9 +344,9 @@ __global__ __launch_bounds__(VG_THREADS) void vit_gemm_kernel(VGemmArgs g) {
   }
 }
 
-extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const float* bias, const float* table, int period,
-                               void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
-                               int dtype, void* stream) {
+extern "C" int maavss_vit_gemm_stats(const void* A, int lda, const void* W, const float* bias, const float* table, int period,
+                                     void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
+                                     float* row_stats, int dtype, void* stream) {
   MAAVSS_CHECK_ARG(A && W && C && M > 0, "vit_gemm: bad arguments");
   MAAVSS_CHECK_ARG(N % VG_BN == 0 && K % VG_BK == 0 && K >= VG_BK, "vit_gemm: N must be a multiple of 128 and K of 64 (N=%d K=%d)", N, K);
   MAAVSS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0, "vit_gemm: leading dimensions must be multiples of 8");
@@ -343,7 +354,9 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
   MAAVSS_CHECK_ARG(epilogue == EPI_F32_ROWTABLE ? (table && period > 0) : (bias != nullptr), "vit_gemm: missing bias/table");
   MAAVSS_CHECK_ARG(M < (1LL << 31), "vit_gemm: M too large");
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_gemm: dtype must be 0 (bf16) or 2 (f16)");
+  MAAVSS_CHECK_ARG(!row_stats || epilogue >= EPI_F32_BIAS_RESID, "vit_gemm: row statistics come with the f32 epilogues (2, 3) only");
   VGemmArgs g;
+  g.row_stats = row_stats;
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.table = table; g.C = C;
   g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.period = period;
   g.qscale_cols = qscale_cols; g.qscale = qscale;
@@ -371,4 +384,10 @@ extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const floa
 #undef VG_LAUNCH2
   MAAVSS_LAUNCH_CHECK("vit_gemm_kernel");
   return MAAVSS_OK;
+}
+
+extern "C" int maavss_vit_gemm(const void* A, int lda, const void* W, const float* bias, const float* table, int period,
+                               void* C, int ldc, int64_t M, int N, int K, int epilogue, int qscale_cols, float qscale,
+                               int dtype, void* stream) {
+  return maavss_vit_gemm_stats(A, lda, W, bias, table, period, C, ldc, M, N, K, epilogue, qscale_cols, qscale, nullptr, dtype, stream);
 }

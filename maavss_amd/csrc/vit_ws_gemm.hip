@@ -34,6 +34,8 @@
 
 struct WsArgs {
   const bf16_t* A;       // 16-bit [ceil(M/64)*64][384]
+  const float* X;        // LN = 2 instead of A: f32 [ceil(M/64)*64][384], normalised on the way into LDS
+  const float* row_stats;  // LN = 2: [M][3][2] = (mean, sum of squared deviations) of the three 128-column thirds of each row of X
   const bf16_t* W;       // 16-bit [N][384]
   const float* bias;     // [N]
   void* C;               // 16-bit [c_rows][ldc] (epi 0, 1) or f32 [c_rows][ldc] (epi 2, read-modify-write)
@@ -49,8 +51,11 @@ struct WsArgs {
   int panels;            // ceil(M / 64)
 };
 
-template <int EPI, bool LN_OUT, int MODE>
+template <int EPI, int LN, int MODE>
 __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
+  constexpr bool LN_OUT = LN == 1, LN_IN = LN == 2;
+  static_assert(!LN_OUT || EPI == 2, "LayerNorm of the output rows comes with the residual epilogue");
+  static_assert(!LN_IN || EPI == 0, "LayerNorm on the way in is wired for the 16-bit bias epilogue (attn.qkv)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* panels_lds = smem;                                                       // 2 x 48 KiB
   float* bias_lds = reinterpret_cast<float*>(smem + WS_BUFS * WS_PANEL_BYTES);   // [384] (+ [384] gamma, [384] beta, stats)
@@ -123,8 +128,56 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
     char* dst_ = panels_lds + (buf) * WS_PANEL_BYTES;                                                             \
     WS_DEPOSIT_HALF_ONE(part, 0, stg0) WS_DEPOSIT_HALF_ONE(part, 1, stg1)                                         \
   }
+  // LN = 2 (norm1 -> attn.qkv): the rows arrive as f32 and are LayerNorm-ed on the way into LDS.  A half panel (32 rows) of f32
+  // is as many bytes as a whole 16-bit panel: the same four loads per lane, one half per half-panel step.  Row statistics:
+  // the producer of X (vit_gemm's f32 epilogues) left (mean, M2) of each 128-column third; lane l loads the three pairs of
+  // row l of the panel AFTER next together with the first half's fetch (same hand-counted wait), merges them (parallel-variance
+  // formula) and wave 0 puts (mean, rstd) into a three-slot LDS table, which the next panel barrier publishes.
+  float4 st01;
+  float2 st2;
+#define WS_FETCH_X(hp, with_stats, srow)                                                                           \
+  {                                                                                                               \
+    const char* src_ = reinterpret_cast<const char*>(g.X) + (int64_t)(hp) * WS_PANEL_BYTES + (wv * 256 + lane) * 16; \
+    if (with_stats) {                                                                                             \
+      const char* sp_ = reinterpret_cast<const char*>(g.row_stats) + (int64_t)(srow) * 24;                         \
+      asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:1024\n\t"            \
+                   "global_load_dwordx4 %2, %6, off offset:2048\n\tglobal_load_dwordx4 %3, %6, off offset:3072\n\t" \
+                   "global_load_dwordx4 %4, %7, off\n\tglobal_load_dwordx2 %5, %7, off offset:16"                  \
+                   : "=&v"(stg0), "=&v"(stg1), "=&v"(stg2), "=&v"(stg3), "=&v"(st01), "=&v"(st2) : "v"(src_), "v"(sp_) : "memory"); \
+    } else {                                                                                                      \
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"            \
+                   "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"    \
+                   : "=&v"(stg0), "=&v"(stg1), "=&v"(stg2), "=&v"(stg3) : "v"(src_) : "memory");                   \
+    }                                                                                                             \
+  }
+  float2* table_lds = stat_lds;      // [3][64] (mean, rstd); LN = 1 uses the same bytes for its partials
+  auto merge_stats = [&](const float4& a, const float2& b) __attribute__((always_inline)) {
+    const float mean = (a.x + a.z + b.x) * (1.f / 3.f);
+    const float d0 = a.x - mean, d1 = a.z - mean, d2 = b.x - mean;
+    const float m2 = (a.y + a.w + b.y) + 128.f * (d0 * d0 + d1 * d1 + d2 * d2);
+    return make_float2(mean, rsqrtf(m2 * (1.f / WS_K) + g.ln_eps));
+  };
+  // chunk q = 64 (4 wv + i) + lane of a half = 4 floats of row q / 96 (+ 32 part), columns 4 (q % 96)...: normalise, round,
+  // 8 bytes to LDS (same swizzled image as the 16-bit path)
+  auto deposit_ln_one = [&](char* dst, const float2* tab, int part, int i, const u32x4& raw, int ln) __attribute__((always_inline)) {
+    const int q = (wv * 4 + i) * 64 + ln, r = q / 96, c4 = q - r * 96, rr = 32 * part + r;
+    const float2 ms = tab[rr];
+    const float4 gg = *reinterpret_cast<const float4*>(gam_lds + 4 * c4), bb = *reinterpret_cast<const float4*>(bet_lds + 4 * c4);
+    const float4 v = __builtin_bit_cast(float4, raw);
+    const uint2 o = make_uint2(pack2<MODE>((v.x - ms.x) * ms.y * gg.x + bb.x, (v.y - ms.x) * ms.y * gg.y + bb.y),
+                               pack2<MODE>((v.z - ms.x) * ms.y * gg.z + bb.z, (v.w - ms.x) * ms.y * gg.w + bb.w));
+    *reinterpret_cast<uint2*>(dst + rr * (WS_K * 2) + (((c4 >> 1) ^ (rr & 15)) << 4) + (c4 & 1) * 8) = o;
+  };
+#define WS_DEPOSIT_LN(buf, tab, part)                                                                             \
+  {                                                                                                               \
+    int ln_ = lane;                                                                                               \
+    asm volatile("" : "+v"(ln_));                                                                                 \
+    char* dst_ = panels_lds + (buf) * WS_PANEL_BYTES;                                                             \
+    deposit_ln_one(dst_, tab, part, 0, stg0, ln_); deposit_ln_one(dst_, tab, part, 1, stg1, ln_);                 \
+    deposit_ln_one(dst_, tab, part, 2, stg2, ln_); deposit_ln_one(dst_, tab, part, 3, stg3, ln_);                 \
+  }
   constexpr bool SPLIT = EPI == 2;
-  WS_FETCH(p0)
+  if constexpr (!LN_IN) WS_FETCH(p0)
 
   // ---- stationary weights.  MFMA row i = 8 q + 4 h + r of the A operand is fed with weight row n0 + pi(i),
   // pi(i) = 16 (q >> 1) + 8 h + 4 (q & 1) + r: the accumulator registers (q, r) of a lane (column = activation row, h = lane
@@ -138,10 +191,27 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   }
   if (tid < WS_SLICE) {
     bias_lds[tid] = g.bias[slice * WS_SLICE + tid];
-    if constexpr (LN_OUT) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
+    if constexpr (LN != 0) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
   }
-  WS_WAIT_FETCH(0)
-  WS_DEPOSIT(0)
+  if constexpr (!LN_IN) {
+    WS_WAIT_FETCH(0)
+    WS_DEPOSIT(0)
+  } else {
+    // statistics of the first two panels (plain loads), then the first panel half by half
+    if (wv < 2 && p0 + wv < p1) {
+      int row = (p0 + wv) * WS_BM + lane;
+      row = row < g.M ? row : g.M - 1;
+      const float* sp = g.row_stats + (int64_t)row * 6;
+      table_lds[wv * WS_BM + lane] = merge_stats(*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float2*>(sp + 4));
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+      WS_FETCH_X(2 * p0 + part, false, 0)
+      WS_WAIT_FETCH(0)
+      WS_DEPOSIT_LN(0, table_lds, part)
+    }
+  }
   // fragment read address: activation row r32 (+ 32 h2), chunk 2 kb + half, kb = 8 a + b:
   //   ((2 b + half) ^ (r32 & 15)) << 4  =  (((b << 5) ^ ((r32 & 14) << 4))) + ((half ^ (r32 & 1)) << 4)
   const int frag_r = r32 * (WS_K * 2) + ((half ^ (r32 & 1)) << 4), frag_x = (r32 & 14) << 4;
@@ -154,11 +224,20 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(abl & 16)) __builtin_amdgcn_s_barrier();      // panel p is in LDS for everybody; everybody is done reading panel p-1
     const bool more = p + 1 < p1 && !((abl & 2) && it > 0);
-    if constexpr (!SPLIT) { if (more) WS_FETCH(p + 1) }   // in flight during this panel's MFMAs, written to the other buffer at the end
+    if constexpr (!SPLIT && !LN_IN) { if (more) WS_FETCH(p + 1) }   // in flight during this panel's MFMAs, written to the other buffer at the end
     const int m0 = p * WS_BM;
 #pragma unroll 1
     for (int h2 = 0; h2 < 2; ++h2) {
       if constexpr (SPLIT) { if (more) WS_FETCH_HALF(p + 1, h2) }
+      bool stats_next = false;
+      if constexpr (LN_IN) {
+        if (more) {
+          stats_next = h2 == 0 && p + 2 < p1;
+          int srow = (p + 2) * WS_BM + lane;
+          srow = srow < g.M ? srow : g.M - 1;
+          WS_FETCH_X(2 * (p + 1) + h2, stats_next, srow)
+        }
+      }
       const char* pb = panels_lds + buf * WS_PANEL_BYTES + h2 * (32 * WS_K * 2) + frag_r;
       f32x16 acc;
 #pragma unroll
@@ -173,7 +252,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
       };
       // fragment reads kept in flight ahead of the MFMA that consumes them (the residual epilogues are HBM-bound and short of
       // registers: one)
-      constexpr int WS_DEPTH = EPI == 2 ? 1 : 3;
+      constexpr int WS_DEPTH = EPI == 2 ? 1 : LN_IN ? 2 : 3;
       bf16x8 f[WS_DEPTH + 1];
 #pragma unroll
       for (int kb = 0; kb < WS_DEPTH; ++kb) f[kb] = rd(kb);
@@ -265,14 +344,57 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           WS_DEPOSIT_HALF(buf ^ 1, h2)
         }
       }
+      if constexpr (LN_IN) {
+        if (more) {
+          WS_WAIT_FETCH(S / 2)
+          WS_DEPOSIT_LN(buf ^ 1, table_lds + ((it + 1) % 3) * WS_BM, h2)
+          if (stats_next && wv == 0) table_lds[((it + 2) % 3) * WS_BM + lane] = merge_stats(st01, st2);
+        }
+      }
     }
-    if constexpr (!SPLIT) {
+    if constexpr (!SPLIT && !LN_IN) {
       if (more) {
         WS_WAIT_FETCH(S)               // younger than the fetch: exactly this panel's S epilogue operations
         WS_DEPOSIT(buf ^ 1)            // the buffer panel p-1 left at this iteration's barrier
       }
     }
   }
+}
+
+static int ws_gemm_launch(const char* who, const void* A, const float* X, const float* row_stats, const void* W, const float* bias,
+                          void* C, int ldc, int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream) {
+  static int n_cu_dev[64] = {0};
+  int dev = 0;
+  MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "%s: cannot query the device", who);
+  if (!n_cu_dev[dev]) {
+    hipDeviceProp_t prop;
+    MAAVSS_CHECK_ARG(hipGetDeviceProperties(&prop, dev) == hipSuccess, "%s: cannot query the device", who);
+    n_cu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int cu_per_xcd = n_cu_dev[dev] / 8 > 0 ? n_cu_dev[dev] / 8 : 1;
+  WsArgs g;
+  g.A = (const bf16_t*)A; g.X = X; g.row_stats = row_stats; g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.XN = (bf16_t*)xn_out;
+  g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
+  g.M = (int)M; g.N = N; g.ldc = ldc; g.qscale_cols = qscale_cols; g.qscale = qscale;
+  g.ns = N / WS_SLICE;
+  MAAVSS_CHECK_ARG(g.ns <= cu_per_xcd, "%s: N too large for one XCD's CUs", who);
+  g.groups_per_xcd = cu_per_xcd / g.ns;
+  g.panels = cdiv(M, WS_BM);
+  const size_t smem = WS_BUFS * WS_PANEL_BYTES + 3 * WS_SLICE * sizeof(float) + WS_BM * WS_WAVES * sizeof(float2);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(8 * cu_per_xcd), block(WS_THREADS);
+#define WS_LAUNCH3(E, L, D)                                                                                           \
+  {                                                                                                                   \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_ws_gemm_kernel<E, L, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                      \
+  }
+#define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
+  if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
+#undef WS_LAUNCH3
+#undef WS_LAUNCH
+  MAAVSS_LAUNCH_CHECK("vit_ws_gemm_kernel");
+  return MAAVSS_OK;
 }
 
 extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, const float* bias, void* C, int ldc, int64_t c_rows,
@@ -290,35 +412,20 @@ extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const 
                    (long)cdiv(M, WS_BM) * WS_BM, (long)c_rows);
   MAAVSS_CHECK_ARG(!xn_out || (epilogue == 2 && N == WS_SLICE && ln_gamma && ln_beta),
                    "vit_ws_gemm: the LayerNorm output needs epilogue 2, N = 384 and the LayerNorm parameters");
-  static int n_cu_dev[64] = {0};
-  int dev = 0;
-  MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "vit_ws_gemm: cannot query the device");
-  if (!n_cu_dev[dev]) {
-    hipDeviceProp_t prop;
-    MAAVSS_CHECK_ARG(hipGetDeviceProperties(&prop, dev) == hipSuccess, "vit_ws_gemm: cannot query the device");
-    n_cu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  const int cu_per_xcd = n_cu_dev[dev] / 8 > 0 ? n_cu_dev[dev] / 8 : 1;
-  WsArgs g;
-  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.XN = (bf16_t*)xn_out;
-  g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
-  g.M = (int)M; g.N = N; g.ldc = ldc; g.qscale_cols = qscale_cols; g.qscale = qscale;
-  g.ns = N / WS_SLICE;
-  MAAVSS_CHECK_ARG(g.ns <= cu_per_xcd, "vit_ws_gemm: N too large for one XCD's CUs");
-  g.groups_per_xcd = cu_per_xcd / g.ns;
-  g.panels = cdiv(M, WS_BM);
-  const size_t smem = WS_BUFS * WS_PANEL_BYTES + 3 * WS_SLICE * sizeof(float) + WS_BM * WS_WAVES * sizeof(float2);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(8 * cu_per_xcd), block(WS_THREADS);
-#define WS_LAUNCH3(E, L, D)                                                                                           \
-  {                                                                                                                   \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_ws_gemm_kernel<E, L, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                      \
-  }
-#define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
-  if (epilogue == 0) WS_LAUNCH(0, false) else if (epilogue == 1) WS_LAUNCH(1, false) else if (xn_out) WS_LAUNCH(2, true) else WS_LAUNCH(2, false)
-#undef WS_LAUNCH3
-#undef WS_LAUNCH
-  MAAVSS_LAUNCH_CHECK("vit_ws_gemm_kernel");
-  return MAAVSS_OK;
+  return ws_gemm_launch("vit_ws_gemm", A, nullptr, nullptr, W, bias, C, ldc, M, N, epilogue, qscale_cols, qscale, xn_out, ln_gamma, ln_beta,
+                        ln_eps, dtype, stream);
+}
+
+extern "C" int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
+                                     float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N,
+                                     int qscale_cols, float qscale, int dtype, void* stream) {
+  MAAVSS_CHECK_ARG(X && row_stats && ln_gamma && ln_beta && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln: bad arguments");
+  MAAVSS_CHECK_ARG(N % WS_SLICE == 0 && N >= WS_SLICE, "vit_ws_gemm_ln: N must be a multiple of 384 (got %d)", N);
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm_ln: dtype must be 0 (bf16) or 2 (f16)");
+  MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM && c_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM,
+                   "vit_ws_gemm_ln: X and C need ceil(M/64)*64 = %ld allocated rows (got %ld, %ld): whole panels are read and stored",
+                   (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows, (long)c_rows);
+  MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm_ln: ldc must be a multiple of 8, qscale_cols a multiple of 384");
+  return ws_gemm_launch("vit_ws_gemm_ln", nullptr, X, row_stats, W, bias, C, ldc, M, N, 0, qscale_cols, qscale, nullptr, ln_gamma, ln_beta, ln_eps,
+                        dtype, stream);
 }

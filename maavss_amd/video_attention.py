@@ -122,8 +122,10 @@ class VideoAttention:
         self.device = torch.device(device)
         self.frames_per_launch = frames_per_launch
         self.fused_panel_gemm = os.environ.get("MAAVSS_VIT_PANEL_GEMM", "1") != "0"   # LN+GEMM panel kernel for K=384
-        # K = 384 layers on the weight-stationary kernel (maavss_vit_ws_gemm): norm1 as its own pass, norm2 written by proj
+        # K = 384 layers on the weight-stationary kernel (maavss_vit_ws_gemm): norm1 applied while qkv loads x (row statistics
+        # from the kernels that wrote x), norm2 written by proj
         self.ws_gemm = os.environ.get("MAAVSS_VIT_WS_GEMM", "1") != "0"
+        self.ws_ln_in = os.environ.get("MAAVSS_VIT_WS_LN", "1") != "0"     # measurement switch: 0 = norm1 as its own pass
         self.model = self.__load_model(path_to_weights)
         self._dev = None          # device-side weight images, built lazily
         self._tables = {}
@@ -192,6 +194,9 @@ class VideoAttention:
         a = torch.empty(rows, 192, device=dev, dtype=tdt)
         x = torch.empty(rpad, DIM, device=dev, dtype=torch.float32)
         xn = torch.empty(rpad, DIM, device=dev, dtype=tdt) if (self.ws_gemm or not self.fused_panel_gemm) else None
+        # per-row LayerNorm partials of x over its three 128-column thirds, written by the kernels that store x (patch
+        # embedding, fc2) and merged by the qkv kernel, which normalises x on the way in: norm1 never runs as a pass
+        stats = torch.empty(rows, 3, 2, device=dev, dtype=torch.float32) if self.ws_gemm else None
         qkv = torch.empty(rpad, 3 * DIM, device=dev, dtype=tdt)
         att_o = torch.empty(rpad, DIM, device=dev, dtype=tdt)
         hid = torch.empty(rpad, MLP, device=dev, dtype=tdt)
@@ -199,8 +204,8 @@ class VideoAttention:
         if self.attn_fp8:
             ws8 = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", f, ntok, HEADS), device=dev, dtype=torch.uint8)
         call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, dt, st)
-        call("maavss_vit_gemm", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
-             EPI_F32_ROWTABLE, 0, 1.0, dt, st)
+        call("maavss_vit_gemm_stats", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
+             EPI_F32_ROWTABLE, 0, 1.0, ptr(stats) if (self.ws_gemm and self.ws_ln_in) else None, dt, st)
         qs = 0.125 * 1.4426950408889634          # q *= log2(e)/sqrt(64): the attention kernels run softmax on exp2
         for i in range(DEPTH):
             b = wts[i]
@@ -208,10 +213,14 @@ class VideoAttention:
             # are [q; k; v], so N = 2 DIM computes exactly those two thirds into the same [rows, 3 DIM] buffer
             nqkv = 2 * DIM if i == DEPTH - 1 else 3 * DIM
             if self.ws_gemm:
-                # norm1 (own pass), then qkv with the weights stationary in registers
-                call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, dt, st)
-                call("maavss_vit_ws_gemm", ptr(xn), DIM, rpad, ptr(b["qkv_w"]), ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv,
-                     EPI_BF16_BIAS, DIM, qs, None, None, None, LN_EPS, dt, st)
+                if not self.ws_ln_in:
+                    call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, dt, st)
+                    call("maavss_vit_ws_gemm", ptr(xn), DIM, rpad, ptr(b["qkv_w"]), ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv,
+                         EPI_BF16_BIAS, DIM, qs, None, None, None, LN_EPS, dt, st)
+                else:
+                  # norm1 + qkv: weights stationary in registers, x normalised on its way into LDS
+                  call("maavss_vit_ws_gemm_ln", ptr(x), rpad, ptr(stats), ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
+                       ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv, DIM, qs, dt, st)
             elif self.fused_panel_gemm:
                 # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
@@ -243,8 +252,8 @@ class VideoAttention:
                 call("maavss_vit_layernorm", ptr(x), ptr(b["n2w"]), ptr(b["n2b"]), ptr(xn), rows, DIM, LN_EPS, dt, st)
                 call("maavss_vit_gemm", ptr(xn), DIM, ptr(b["fc1_w"]), ptr(b["fc1_b"]), None, 0, ptr(hid), MLP, rows, MLP,
                      DIM, EPI_BF16_BIAS_GELU, 0, 1.0, dt, st)
-            call("maavss_vit_gemm", ptr(hid), MLP, ptr(b["fc2_w"]), ptr(b["fc2_b"]), None, 0, ptr(x), DIM, rows, DIM, MLP,
-                 EPI_F32_BIAS_RESID, 0, 1.0, dt, st)
+            call("maavss_vit_gemm_stats", ptr(hid), MLP, ptr(b["fc2_w"]), ptr(b["fc2_b"]), None, 0, ptr(x), DIM, rows, DIM, MLP,
+                 EPI_F32_BIAS_RESID, 0, 1.0, ptr(stats) if (self.ws_gemm and self.ws_ln_in) else None, dt, st)
         att = torch.empty(f, HEADS, ntok - 1, device=dev, dtype=torch.float32)
         call("maavss_vit_cls_attn", ptr(qkv), ptr(att), f, ntok, HEADS, 3 * DIM, dt, st)
         return att

@@ -168,6 +168,40 @@ def test_vit_ws_gemm(m, n, dt):
               m, n, 2, 0, 1.0, None, None, None, 1e-6, dt, _st())
 
 
+@pytest.mark.parametrize("dt", [0, 2])
+@pytest.mark.parametrize("m,n", [(1000, 1152), (16 * 1025, 768), (64 * 300 + 1, 1152), (130, 384)])
+def test_vit_ws_gemm_with_layernorm_on_the_way_in(m, n, dt):
+    """norm1 -> qkv without a LayerNorm pass: vit_gemm_stats leaves per-row (mean, M2) partials of the residual rows it
+    stores, vit_ws_gemm_ln merges them and normalises x while loading it.  Against torch: LayerNorm in f32, the
+    normalised rows rounded to the 16-bit format, f32 accumulate."""
+    k = 384
+    mp = (m + 63) // 64 * 64
+    # x = what a residual GEMM stored (with its statistics): x0 + hid @ w2^T + b2, K = 128
+    hid, w2, b2 = rd(rnd(m, 128, seed=11), dt), rd(rnd(k, 128, seed=12, scale=0.2), dt), rnd(k, seed=13, scale=0.1)
+    x0 = rnd(m, k, seed=1, scale=1.5) + 0.3
+    xc = torch.full((mp, k), float("nan"), device="cuda")
+    xc[:m] = x0.cuda()
+    stats = torch.full((m, 3, 2), float("nan"), device="cuda")
+    hc, w2c, b2c = hid.cuda(), w2.cuda(), b2.cuda()
+    _call("maavss_vit_gemm_stats", hc.data_ptr(), 128, w2c.data_ptr(), b2c.data_ptr(), None, 0, xc.data_ptr(), k, m, k, 128, 2, 0, 1.0,
+          stats.data_ptr(), dt, _st())
+    x = xc[:m].cpu()
+    np.testing.assert_allclose(x.numpy(), (x0 + hid.float() @ w2.float().t() + b2).numpy(), rtol=1e-4, atol=3e-4)
+    thirds = x.view(m, 3, 128)
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), thirds.mean(-1).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(stats[..., 1].cpu().numpy(), ((thirds - thirds.mean(-1, keepdim=True)) ** 2).sum(-1).numpy(), rtol=1e-4, atol=1e-3)
+    gam, bet = 1 + 0.1 * rnd(k, seed=2), 0.1 * rnd(k, seed=3)
+    w, bias = rd(rnd(n, k, seed=4, scale=k ** -0.5), dt), rnd(n, seed=5, scale=0.1)
+    xn = rd(F.layer_norm(x, (k,), gam, bet, 1e-6), dt).float()
+    want = xn @ w.float().t() + bias
+    want[:, :384] *= 0.125
+    gc, bc, wc, biasc = gam.cuda(), bet.cuda(), w.cuda(), bias.cuda()
+    c = torch.empty(mp, n, dtype=DT[dt], device="cuda")
+    _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
+          c.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    np.testing.assert_allclose(c[:m].float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
+
+
 def test_vit_layernorm_and_patchify():
     rows = 1003
     x, g, b = rnd(rows, 384, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(384, seed=2), 0.1 * rnd(384, seed=3)
