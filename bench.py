@@ -222,12 +222,14 @@ def main():
         summ = timer.summary()
         # ---- roofline of the dominant kernel family (by accumulated HIP-event time)
         def flops_of(name, a):
-            if name == "maavss_vit_gemm":
+            if name in ("maavss_vit_gemm", "maavss_vit_gemm_stats"):
                 return 2.0 * a[8] * a[9] * a[10]                  # M, N, K
             if name == "maavss_vit_panel_gemm":
                 return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_ws_gemm":
                 return 2.0 * a[8] * a[9] * 384                    # M, N, K = 384 (LayerNorm output flops not counted)
+            if name == "maavss_vit_ws_gemm_ln":
+                return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
             if name == "maavss_vit_attn_fp8":
@@ -235,16 +237,20 @@ def main():
             return 0.0
         def bytes_of(name, a):
             """Algorithmic HBM bytes of one launch: every operand read once, every result written once."""
-            if name == "maavss_vit_gemm":
+            if name in ("maavss_vit_gemm", "maavss_vit_gemm_stats"):
                 m, n, k, epi = a[8], a[9], a[10], a[11]
                 out = {2: 8.0, 3: 4.0}.get(epi, 2.0)                # f32 read-modify-write / f32 / bf16
-                return 2.0 * m * k + 2.0 * n * k + out * m * n
+                stats = 8.0 * m * (n // 128) if (name.endswith("_stats") and a[14]) else 0.0   # (mean, M2) per row and 128-column tile
+                return 2.0 * m * k + 2.0 * n * k + out * m * n + stats
             if name == "maavss_vit_panel_gemm":
                 m, n, epi = a[11], a[12], a[13]
                 return m * 384 * (4.0 if a[0] else 2.0) + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n
             if name == "maavss_vit_ws_gemm":
                 m, n, epi = a[8], a[9], a[10]                       # + the LayerNorm-ed 16-bit copy of the rows when asked for
                 return 2.0 * m * 384 + 2.0 * n * 384 + (8.0 if epi == 2 else 2.0) * m * n + (2.0 * m * 384 if a[13] else 0.0)
+            if name == "maavss_vit_ws_gemm_ln":
+                m, n = a[11], a[12]                                 # f32 rows + their 24-byte statistics in, 16-bit out
+                return (4.0 * 384 + 24.0) * m + 2.0 * n * 384 + 2.0 * m * n
             if name == "maavss_vit_attn":
                 return a[2] * a[3] * (1152 + 384) * 2.0             # qkv in, attention output out, bf16
             if name == "maavss_vit_attn_fp8":
@@ -287,7 +293,8 @@ def main():
             if bytes_:
                 row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
             stages[name.replace("maavss_", "")] = row
-        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_gemm"):
+        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
+                   "maavss_vit_gemm", "maavss_vit_gemm_stats"):
             if nm in summ:
                 stage_row(nm, sum(flops_of(nm, a) for a in summ[nm]["args"]), sum(bytes_of(nm, a) for a in summ[nm]["args"]))
         if "maavss_stft_fwd" in summ:      # audio in (4 B/sample) + y and x out (2 planes x T_a x F x 4 B each)
