@@ -329,12 +329,18 @@ def main():
         if args.verbose:
             shapes = {}
             for name, a, e0, e1 in timer.records:
-                if name == "maavss_vit_gemm":
+                if name in ("maavss_vit_gemm", "maavss_vit_gemm_stats"):
                     key = f"vit_gemm epi{a[11]} M{a[8]} N{a[9]} K{a[10]}"
                     d = shapes.setdefault(key, [0, 0.0, 0.0])
                     d[0] += 1
                     d[1] += e0.elapsed_time(e1)
                     d[2] += 2.0 * a[8] * a[9] * a[10]
+                if name == "maavss_gemm_f32":      # the Linear / LSTM-projection GEMMs: weight streaming at M = batch
+                    key = f"gemm_f32 M{a[3]} N{a[4]} K{a[5]} ta{a[9]} tb{a[10]} tc{a[11]} act{a[12]} beta{a[14]} splitk{a[16]}"
+                    d = shapes.setdefault(key, [0, 0.0, 0.0])
+                    d[0] += 1
+                    d[1] += e0.elapsed_time(e1)
+                    d[2] += 2.0 * a[3] * a[4] * a[5]
             for key, (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 print(f"[bench] {key}: {n} launches, {ms / n * 1e3:.1f} us avg, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
             print(f"[bench] sum of kernel time {sum(v['ms'] for v in summ.values()) / args.steps:.2f} ms/step, "

@@ -178,6 +178,9 @@ static void launch_gemm(GemmArgs g, int cfg, hipStream_t st) {
   }
 }
 
+int maavss_linear_skinny_try(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
+                             int transC, int64_t M, int64_t N, int64_t K, float alpha, int beta, int act, hipStream_t st, int* taken);
+
 extern "C" int maavss_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
                                float* C, int64_t ldc, int transC, int64_t M, int64_t N, int64_t K, float alpha,
                                int beta, int act, int split_k, int precise, void* stream) {
@@ -188,6 +191,11 @@ extern "C" int maavss_gemm_f32(const float* A, int64_t lda, int transA, const fl
   MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "gemm: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   MAAVSS_CHECK_ARG(act >= 0 && act <= 2, "gemm: act must be 0 (none), 1 (tanh) or 2 (sigmoid)");
   hipStream_t st = (hipStream_t)stream;
+  if (precise == MODE_F32 && split_k <= 0) {   // the Linear layers at M = batch: dedicated weight-streaming forms (linear_skinny.hip)
+    int taken = 0;
+    const int rc = maavss_linear_skinny_try(A, lda, transA, B, ldb, transB, C, ldc, transC, M, N, K, alpha, beta, act, st, &taken);
+    if (rc != MAAVSS_OK || taken) return rc;
+  }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;

@@ -37,6 +37,14 @@ def close(got, want, rtol, atol, msg=""):
     (32, 8192, 4096, False, True),     # dX = dY W
     (1024, 256, 512, True, True),      # dW_hh
     (130, 70, 100, False, False),      # ragged everything
+    (32, 4096, 8192, False, False),    # fc1 forward at the benched batch: weight-streaming form, 16 K slices (atomics)
+    (32, 12544, 512, False, False),    # v_fc1 forward (112^2): one K slice, direct stores
+    (32, 512, 12544, False, True),     # v_fc1 input gradient: 98 N slices
+    (4096, 8192, 32, True, True),      # fc1 weight gradient at the benched batch
+    (12544, 512, 32, True, True),      # v_fc1 weight gradient
+    (5, 1000, 528, False, False),      # skinny forms, ragged: rows, columns and the last K slice
+    (7, 780, 300, False, True),
+    (300, 780, 7, True, True),
 ])
 def test_gemm(m, n, k, ta, tb, precise):
     from maavss_amd import ops
@@ -61,6 +69,25 @@ def test_gemm_epilogues():
     close(out, c0 + z, 1e-4, 1e-5)
     outt = ops.gemm(a.cuda(), b.cuda(), precise=True, trans_c=True)
     close(outt, z.t().contiguous(), 1e-4, 1e-5)
+    # the weight-streaming forms of the Linear layers (linear_skinny.hip): activation and accumulate epilogues, with and without
+    # a K / N split (= atomics + separate activation pass)
+    for n, k in ((1024, 512), (1024, 2048)):
+        a, b = rnd(32, k, seed=6, scale=0.2), rnd(n, k, seed=7, scale=0.1)
+        z = a @ b.t()
+        close(ops.gemm(a.cuda(), b.cuda(), act=ops.ACT_SIGMOID, precise=True), torch.sigmoid(z), 1e-4, 2e-5)
+        c0 = rnd(32, n, seed=8)
+        out = c0.clone().cuda()
+        ops.gemm(a.cuda(), b.cuda(), out=out, beta=1, precise=True)
+        close(out, c0 + z, 1e-4, 2e-5)
+        dy = rnd(32, n, seed=9, scale=0.2)
+        dx0 = rnd(32, k, seed=10)
+        out = dx0.clone().cuda()
+        ops.gemm(dy.cuda(), b.cuda(), trans_b=True, out=out, beta=1, precise=True)          # dX += dY W
+        close(out, dx0 + dy @ b, 1e-4, 5e-5)
+        dw0 = rnd(n, k, seed=11)
+        out = dw0.clone().cuda()
+        ops.gemm(dy.cuda(), a.cuda(), trans_a=True, trans_b=True, out=out, beta=1, precise=True)   # dW += dY^T X
+        close(out, dw0 + dy.t() @ a, 1e-4, 2e-5)
 
 
 # ----------------------------------------------------------------------------------------------- conv3d
