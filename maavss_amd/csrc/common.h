@@ -130,6 +130,14 @@ __device__ __forceinline__ float rows4_sum(float v) {
   lane_swap32(a + b, a, b);
   return a + b;
 }
+// sum over the 16 lanes of a lane's DPP row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1, 0xf>(v, 0.f);
+  v += dpp_f32<0x4E, 0xf>(v, 0.f);
+  v += dpp_f32<0x141, 0xf>(v, 0.f);
+  v += dpp_f32<0x140, 0xf>(v, 0.f);
+  return v;
+}
 // sum over the 32 consecutive lanes [0, 32) / [32, 64) a lane belongs to (DPP inside the 16-lane rows, one lane swap across)
 __device__ __forceinline__ float half_wave_sum(float v) {
   v += dpp_f32<0xB1, 0xf>(v, 0.f);

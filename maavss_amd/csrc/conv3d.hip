@@ -708,33 +708,33 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __
     const unsigned e6 = *reinterpret_cast<const unsigned short*>(hb + addr[6]), e7 = *reinterpret_cast<const unsigned short*>(hb + addr[7]);
     const unsigned a0 = e0 | (e1 << 16), a1 = e2 | (e3 << 16), a2 = e4 | (e5 << 16), a3 = e6 | (e7 << 16);
     const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
-    Mma<MODE_F16>::mma(acc[i], fa, fb[kd]);
+    Mma<MODE_F16>::mma(acc[i], fb[kd], fa);     // D[channel][position]: a lane ends up with 4 consecutive channels of one position
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
   step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
   step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
-  // ---- epilogue: lane holds co = l16 of positions (row 4 wv + i, column 4 g + r)
-  float s1 = 0.f, s2 = 0.f;
+  // ---- epilogue: lane holds channels 4 g + (0..3) of position (row 4 wv + i, column l16): 16-byte stores, the 16 lanes of a row
+  // group write 16 consecutive positions = 1 KiB contiguous per store instruction (with positions on the MFMA rows a lane held
+  // one channel of four positions and every store scattered 4-byte pieces)
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int oy = y0 + 4 * wv + i;
+    const int oy = y0 + 4 * wv + i, ox = x0 + l16;
+    if (oy < H && ox < W) {
+      *reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16 + 4 * g) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ox = x0 + 4 * g + r;
-      if (oy < H && ox < W) {
-        const float v = acc[i][r];
-        y[(((int64_t)bt * H + oy) * W + ox) * 16 + l16] = v;
-        s1 += v;
-        s2 += v * v;
-      }
+      for (int r = 0; r < 4; ++r) { s1[r] += acc[i][r]; s2[r] += acc[i][r] * acc[i][r]; }
     }
   }
   if (stat_partials != nullptr) {
-    s1 = rows4_sum(s1);
-    s2 = rows4_sum(s2);
-    if (g == 0) { red[wv][0][l16] = s1; red[wv][1][l16] = s2; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[r] = row16_sum(s1[r]);
+      s2[r] = row16_sum(s2[r]);
+      if (l16 == 0) { red[wv][0][4 * g + r] = s1[r]; red[wv][1][4 * g + r] = s2[r]; }
+    }
     __syncthreads();
     if (tid < 32) {
       const int which = tid >> 4, c = tid & 15;

@@ -9,7 +9,10 @@
 // deterministic reduce kernel.
 #include "mma.h"
 
-template <int MODE, int CI, int CO, int KDN, bool DY16 = false>
+// CIT > CI (64 -> 64 as two workgroups of 32 input channels each, blockIdx.y): x rows hold CIT channels, this workgroup stages
+// and owns channels [CI blockIdx.y, +CI) -- every x byte is still staged once, dy (16-bit) twice; the one-(kd,kh)-per-workgroup
+// kernel staged both fifteen times (0.83 ms per step for this layer, 2.4x its forward).
+template <int MODE, int CI, int CO, int KDN, bool DY16 = false, int CIT = CI>
 __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __restrict__ x, const void* __restrict__ dy_,
                                                                float* __restrict__ partials, int BT, int T, int H, int W,
                                                                int Ho, int Wo, int pad, int tiles_x, int tiles_y,
@@ -30,6 +33,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   const int chunk = xcd * ((nchunk + 7) / 8) + slot / KDG, kdg = slot % KDG;
   if (chunk >= nchunk) return;
   const int kd0 = kdg * KDN;
+  const int ci0 = CIT > CI ? (int)blockIdx.y * CI : 0;
   f32x4 acc[PW][NT];
 #pragma unroll
   for (int p = 0; p < PW; ++p)
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
       const int tt = t + kd0 + kdl - 1, iy = y0 + r - pad, ix = x0 + c - pad;
       xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < XV && tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W)
-        xr[j] = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CI + c4);
+        xr[j] = *reinterpret_cast<const float4*>(x + (((int64_t)(bt + kd0 + kdl - 1) * H + iy) * W + ix) * CIT + ci0 + c4);
     }
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
     const int q = wv + 8 * p;
     if (q < NPAIR) {
       const int tap = q / MT, mi = q % MT;
-      float* out = partials + (((int64_t)chunk * 75 + kd0 * 25 + tap) * CI + mi * 16 + G * 4) * CO;
+      float* out = partials + (((int64_t)chunk * 75 + kd0 * 25 + tap) * CIT + ci0 + mi * 16 + G * 4) * CO;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -172,18 +176,18 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   }
 }
 
-template <int MODE, int CI, int CO, int KDN, bool DY16 = false>
+template <int MODE, int CI, int CO, int KDN, bool DY16 = false, int CIT = CI>
 static void launch_wide(const float* x, const void* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                         int nchunk, hipStream_t st) {
   using E = typename Mma<MODE>::elem;
   const size_t smem = (KDN * 400 * CI + 256 * CO) * sizeof(E);
-  auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN, DY16>;
+  auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN, DY16, CIT>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
   const int tiles_total = BT * tiles_x * tiles_y;
   const int tpc = cdiv(tiles_total, nchunk);
   constexpr int KDG = 3 / KDN;
-  hipLaunchKernelGGL(kern, dim3(KDG * cdiv(nchunk, 8) * 8), dim3(512), smem, st, x, dy, ws, BT, T, H, W, Ho, Wo, pad, tiles_x,
+  hipLaunchKernelGGL(kern, dim3(KDG * cdiv(nchunk, 8) * 8, CIT / CI), dim3(512), smem, st, x, dy, ws, BT, T, H, W, Ho, Wo, pad, tiles_x,
                      tiles_y, tpc, nchunk);
 }
 
@@ -201,5 +205,10 @@ int maavss_conv3d_wgrad_wide_try(const float* x, const void* dy, float* ws, int 
   WIDE(16, 32, 3)
   WIDE(32, 64, 1)
 #undef WIDE
+  if (c_in == 64 && c_out == 64 && mode == MODE_BF16) {       // two 32-channel halves of x per tile (16-bit path only)
+    if (dy16) launch_wide<MODE_BF16, 32, 64, 1, true, 64>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);
+    else launch_wide<MODE_BF16, 32, 64, 1, false, 64>(x, dy, ws, B * T, T, H, W, Ho, Wo, pad, nchunk, st);
+    return 1;
+  }
   return 0;
 }

@@ -86,6 +86,8 @@ def wgrad_chunks(b, t, ho, wo, ci=64, co=64):
         return max(1, min(512, tiles // 2))
     if (ci, co) == (32, 64):
         return max(1, min(256, tiles // 2))
+    if (ci, co) == (64, 64):      # 16-bit path: wide kernel over two 32-channel halves, 3 x 2 workgroups per chunk
+        return max(1, min(85, tiles // 4))
     return max(1, min(64, tiles // 4))
 
 
