@@ -198,7 +198,11 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync_all()
-    timer = _lib.KernelTimer()
+    # HIP events around the entry points the roofline / stage rows are made of (the ViT GEMMs and attention, STFT, Adam); with
+    # --verbose around every entry point (155 launches per step: the event pairs then cost ~0.9 ms of the step)
+    staged = ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
+              "maavss_vit_gemm", "maavss_vit_gemm_stats", "maavss_stft_fwd", "maavss_adam_step")
+    timer = _lib.KernelTimer(only=None if args.verbose else staged)
     _lib.set_timer(timer)
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -81,8 +81,9 @@ class KernelTimer:
     """Optional per-entry-point timing with HIP events recorded on the launch stream (torch's current
     stream is the stream every entry point launches on).  Used by bench.py for the roofline numbers."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (name, args, start_event, end_event)
+        self.only = None if only is None else frozenset(only)   # time these entry points only (an event pair costs ~3 us of stream time)
 
     def summary(self):
         import torch
@@ -105,7 +106,7 @@ def set_timer(timer):
 
 
 def call(name, *args):
-    if _timer is None:
+    if _timer is None or (_timer.only is not None and name not in _timer.only):
         lib().call(name, *args)
         return
     import torch
