@@ -246,13 +246,16 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
         acc[4 * q + 0] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
       }
       auto rd = [&](int kb) __attribute__((always_inline)) {
+        // The GELU epilogue makes fc1 vector-ISSUE bound (PMC: 8.5 VALU instructions per MFMA; a 32x32x16 MFMA leaves room for
+        // six): there the eight fragment addresses are precomputed (registers paid for with one step less of read-ahead).  The
+        // other variants have no registers left and recompute the address per read (one v_xad).
         int fx = frag_x;
-        asm volatile("" : "+v"(fx));   // recomputed per read (one v_xad): eight precomputed addresses would stay live for the whole kernel
+        if constexpr (EPI != 1) asm volatile("" : "+v"(fx));
         return *reinterpret_cast<const bf16x8*>(pb + (((kb & 7) << 5) ^ fx) + (kb >> 3) * 256);
       };
       // fragment reads kept in flight ahead of the MFMA that consumes them (the residual epilogues are HBM-bound and short of
       // registers: one)
-      constexpr int WS_DEPTH = EPI == 2 ? 1 : LN_IN ? 2 : 3;
+      constexpr int WS_DEPTH = EPI == 2 ? 1 : (LN_IN || EPI == 1) ? 2 : 3;
       bf16x8 f[WS_DEPTH + 1];
 #pragma unroll
       for (int kb = 0; kb < WS_DEPTH; ++kb) f[kb] = rd(kb);
