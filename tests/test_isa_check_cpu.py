@@ -1,0 +1,50 @@
+"""The build-time guard of vit_ws_gemm.hip's hand-counted panel fetch (maavss_amd/csrc/check_ws_gemm_isa.py) must actually
+reject the hazards it exists for: a compiler copy / spill of the fetch registers between the inline-asm loads and their
+s_waitcnt, and scratch use.  Synthetic assembly, no GPU and no compiler needed."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_ws_gemm_isa", os.path.join(ROOT, "maavss_amd", "csrc", "check_ws_gemm_isa.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+FETCH = """\t;;#ASMSTART
+\tglobal_load_dwordx4 v[112:115], v[8:9], off
+\tglobal_load_dwordx4 v[116:119], v[8:9], off offset:1024
+\t;;#ASMEND
+"""
+WAIT = """\t;;#ASMSTART
+\ts_waitcnt vmcnt(4)
+\t;;#ASMEND
+"""
+
+
+def kernel(between_loop_fetch_and_wait="\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n", extra=""):
+    return ("_Z18vit_ws_gemm_kernelILi0ELi0ELi2EEv6WsArgs: ; @kernel\n" + FETCH + "\tv_add_u32_e32 v1, v2, v3\n" + WAIT +
+            "\tds_write_b128 v5, v[112:115]\n.LBB0_1:\n\ts_barrier\n" + FETCH + between_loop_fetch_and_wait + WAIT +
+            "\tds_write_b128 v5, v[112:115]\n" + extra + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+
+
+def run(tmp_path, text):
+    p = tmp_path / "k.s"
+    p.write_text(text)
+    return chk.main(str(p))
+
+
+def test_clean_kernel_passes(tmp_path):
+    assert run(tmp_path, kernel()) == 0
+
+
+def test_copy_of_a_pending_register_is_rejected(tmp_path):
+    assert run(tmp_path, kernel("\tv_mov_b64_e32 v[0:1], v[112:113]\n")) == 1
+    assert run(tmp_path, kernel("\tv_add_f32_e32 v117, v117, v2\n")) == 1
+
+
+def test_spill_is_rejected(tmp_path):
+    assert run(tmp_path, kernel(extra="\tscratch_store_dwordx4 off, v[40:43], off\n")) == 1
+
+
+def test_fetch_without_wait_is_rejected(tmp_path):
+    text = kernel().replace(WAIT + "\tds_write_b128 v5, v[112:115]\n\ts_cbranch", "\ts_cbranch")
+    assert run(tmp_path, text) == 1
