@@ -340,11 +340,12 @@ def main():
                     d[1] += e0.elapsed_time(e1)
                     d[2] += 2.0 * a[8] * a[9] * a[10]
                 if name == "maavss_gemm_f32":      # the Linear / LSTM-projection GEMMs: weight streaming at M = batch
-                    key = f"gemm_f32 M{a[3]} N{a[4]} K{a[5]} ta{a[9]} tb{a[10]} tc{a[11]} act{a[12]} beta{a[14]} splitk{a[16]}"
+                    # (A, lda, transA, B, ldb, transB, C, ldc, transC, M, N, K, alpha, beta, act, split_k, precise, stream)
+                    key = f"gemm_f32 M{a[9]} N{a[10]} K{a[11]} ta{a[2]} tb{a[5]} tc{a[8]} act{a[14]} beta{a[13]} splitk{a[15]}"
                     d = shapes.setdefault(key, [0, 0.0, 0.0])
                     d[0] += 1
                     d[1] += e0.elapsed_time(e1)
-                    d[2] += 2.0 * a[3] * a[4] * a[5]
+                    d[2] += 2.0 * a[9] * a[10] * a[11]
             for key, (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 print(f"[bench] {key}: {n} launches, {ms / n * 1e3:.1f} us avg, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
             print(f"[bench] sum of kernel time {sum(v['ms'] for v in summ.values()) / args.steps:.2f} ms/step, "
