@@ -183,7 +183,7 @@ def main():
     attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
 
     def step(i):
-        va.attention_frames(frames, clip_frames=t, out=attn)
+        va.attention_frames(frames, clip_frames=t, out=attn, finite_check="deferred")   # range guard of the half storage, no sync
         x_v = attn.view(b, 1, t, w, w)
         x_stft, y_stft = stft(audio, seed=i)
         y_a = y_stft[:, :, mid * hpf:(mid + 1) * hpf, :]
@@ -221,6 +221,7 @@ def main():
         step(args.warmup + args.steps + i)
     sync_all()
     elapsed_plain = time.perf_counter() - t1
+    va.check_finite()                        # the last step's deferred range flag
 
     if rank == 0:
         summ = timer.summary()

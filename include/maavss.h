@@ -292,6 +292,13 @@ int maavss_vit_attn_fp8(const void* qkv, void* out, void* ws, int frames, int nt
                         void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
                          int clip_frames, int attn_diff /* av_dataset.py:323-326, needs clip_frames > 0 */, void* stream);
+/* Same, and sets *nonfinite_flag (device int32, sticky, never cleared here; null = no check) to 1 when any CLS-attention value
+ * is inf or NaN.  This is the range guard of the IEEE-half storage format (dtype 2) of the extractor: the reference computes in
+ * fp32 (video_attention.py:52), where |activation| > 65504 is harmless; here such a value becomes inf in a 16-bit store,
+ * poisons that frame's residual stream and arrives in this row as NaN -- one check on 6 x n values per frame covers every
+ * upstream store.  The host side (maavss_amd/video_attention.py) raises and names act_dtype="bf16". */
+int maavss_vit_attn_maps_checked(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
+                                 int clip_frames, int attn_diff, int32_t* nonfinite_flag, void* stream);
 
 /* ---- EXTENSION (no reference counterpart): AdaptiveAvgPool2d closing the STFT encoder for frame sizes the
  * reference constructor cannot build (224^2, 384^2; SURVEY.md finding 2).  x NHWC [B][H][W][C]; out/dout

@@ -54,18 +54,24 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float* __restr
 }
 
 // pass 1: small[f][j] = (sum_h att[f][h][j]) * (1/max_j);  fmax[f] = max_j of the scaled map
+// `nonfinite` (optional): sticky flag, set to 1 when a CLS-attention value is inf / NaN.  Every 16-bit overflow upstream (q, k, v,
+// the GELU hidden as IEEE half > 65504) poisons the frame's residual stream and reaches this row as NaN, so this one check on
+// 6 x n values per frame guards the whole extractor without touching its GEMM epilogues.
 __global__ __launch_bounds__(256) void vit_maps_pass1_kernel(const float* __restrict__ att, float* __restrict__ small,
-                                                             float* __restrict__ fmax, int heads, int n) {
+                                                             float* __restrict__ fmax, int heads, int n, int* __restrict__ nonfinite) {
   __shared__ float red[4];
   const int f = blockIdx.x, tid = threadIdx.x;
   const float* ap = att + (int64_t)f * heads * n;
   float mx = -1e30f;
+  bool bad = false;
   for (int j = tid; j < n; j += 256) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += ap[h * n + j];
     small[(int64_t)f * n + j] = s;
+    bad |= !(fabsf(s) <= 3.0e38f);      // false for inf and for NaN
     mx = fmaxf(mx, s);
   }
+  if (nonfinite != nullptr && bad) atomicOr(nonfinite, 1);
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
@@ -160,8 +166,8 @@ extern "C" int maavss_vit_layernorm(const float* x, const float* gamma, const fl
 }
 
 // ws: n_frames * (hp*wp + 1) floats
-extern "C" int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
-                                    int clip_frames, int attn_diff, void* stream) {
+extern "C" int maavss_vit_attn_maps_checked(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
+                                            int clip_frames, int attn_diff, int32_t* nonfinite_flag, void* stream) {
   MAAVSS_CHECK_ARG(att && out && ws && n_frames > 0 && heads > 0, "vit_attn_maps: bad arguments");
   MAAVSS_CHECK_ARG(W % 4 == 0 && H >= 8 && W >= 8, "vit_attn_maps: W must be a multiple of 4");
   MAAVSS_CHECK_ARG(clip_frames == 0 || n_frames % clip_frames == 0, "vit_attn_maps: n_frames must be a multiple of clip_frames");
@@ -170,7 +176,7 @@ extern "C" int maavss_vit_attn_maps(const float* att, float* out, float* ws, int
   float* small = ws;
   float* fmax = ws + n_frames * n;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(vit_maps_pass1_kernel, dim3((unsigned)n_frames), dim3(256), 0, st, att, small, fmax, heads, n);
+  hipLaunchKernelGGL(vit_maps_pass1_kernel, dim3((unsigned)n_frames), dim3(256), 0, st, att, small, fmax, heads, n, nonfinite_flag);
   MAAVSS_LAUNCH_CHECK("vit_maps_pass1_kernel");
   if (attn_diff) {
     hipLaunchKernelGGL(vit_maps_diff_kernel, dim3((unsigned)(n_frames / clip_frames)), dim3(256), 0, st, small, fmax, n, clip_frames);
@@ -181,4 +187,9 @@ extern "C" int maavss_vit_attn_maps(const float* att, float* out, float* ws, int
                      dim3(256), 0, st, small, fmax, out, H, W, hp, wp, clip_frames, total4);
   MAAVSS_LAUNCH_CHECK("vit_maps_pass2_kernel");
   return MAAVSS_OK;
+}
+
+extern "C" int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
+                                    int clip_frames, int attn_diff, void* stream) {
+  return maavss_vit_attn_maps_checked(att, out, ws, n_frames, heads, H, W, clip_frames, attn_diff, nullptr, stream);
 }

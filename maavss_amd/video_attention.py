@@ -129,6 +129,8 @@ class VideoAttention:
         self.model = self.__load_model(path_to_weights)
         self._dev = None          # device-side weight images, built lazily
         self._tables = {}
+        # range guard of the 16-bit storage (see attention_frames): sticky device flag + the pinned host copy of the last call
+        self._flag = self._flag_host = self._flag_event = None
 
     def __load_model(self, pretrained_weights):
         model = ViTSmall8Weights()
@@ -258,13 +260,42 @@ class VideoAttention:
         call("maavss_vit_cls_attn", ptr(qkv), ptr(att), f, ntok, HEADS, 3 * DIM, dt, st)
         return att
 
-    def attention_frames(self, frames, clip_frames=0, out=None, attn_diff=False):
+    def check_finite(self):
+        """Raise if a previous attention_frames(..., finite_check="deferred") call produced a non-finite CLS attention
+        (waits for that call's flag copy only, not for the device)."""
+        if self._flag_event is None:
+            return
+        self._flag_event.synchronize()
+        self._flag_event = None
+        if int(self._flag_host.item()) != 0:
+            self._flag.zero_()
+            self._flag_host.zero_()
+            raise _lib.MaavssError(
+                "VideoAttention: non-finite attention maps -- an activation of the ViT left the range of its 16-bit storage "
+                f"format (act_dtype={self.act_dtype!r}" + (": IEEE half saturates at 65504; build the extractor with "
+                "act_dtype='bf16', which has fp32's exponent range" if self.act_dtype == "f16" else "") +
+                ") or the input frames / weights hold inf or NaN")
+
+    def attention_frames(self, frames, clip_frames=0, out=None, attn_diff=False, finite_check="sync"):
         """Batched GPU path: frames [F,3,H,W] -> attention frames [F,1,H,W] (each /frame max; with
         clip_frames = T additionally /clip max over consecutive groups of T frames, av_dataset.py:328;
         attn_diff=True first replaces each clip's frames by their temporal difference, av_dataset.py:323-326).
         Frames are processed `frames_per_launch` at a time (bounds the activation scratch: ~9.6 MB per frame at
-        224^2); measured on MI355X, fewer and larger launches win (512 frames/group: 75 ms/step vs 88 ms at 64)."""
+        224^2); measured on MI355X, fewer and larger launches win (512 frames/group: 75 ms/step vs 88 ms at 64).
+
+        finite_check: the reference runs the ViT in fp32; here activations are stored in 16 bits and IEEE half (the default)
+        overflows above 65504 -> inf -> NaN maps.  The maps kernel raises a sticky device flag when a CLS-attention value is
+        not finite (every upstream overflow ends there).  "sync" (default): wait for this call and raise MaavssError now;
+        "deferred": copy the flag to pinned host memory asynchronously and raise at the NEXT call / check_finite() -- no
+        host-device synchronisation inside a training step (bench.py); None: no check."""
         _lib.require_cuda(frames)
+        if finite_check not in ("sync", "deferred", None):
+            raise ValueError("finite_check must be 'sync', 'deferred' or None")
+        self.check_finite()                       # a deferred flag of the previous call
+        if finite_check is not None and self._flag is None:
+            self._flag = torch.zeros(1, device=self.device, dtype=torch.int32)
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        flag = self._flag if finite_check is not None else None
         f, _, h, w = frames.shape
         if out is None:
             out = torch.empty(f, 1, h, w, device=frames.device, dtype=torch.float32)
@@ -276,8 +307,14 @@ class VideoAttention:
             e = min(f, s + step)
             att = self.cls_attention(frames[s:e])
             ws = torch.empty((e - s) * (hp * wp + 1), device=frames.device, dtype=torch.float32)
-            call("maavss_vit_attn_maps", ptr(att), ptr(out[s:e]), ptr(ws), e - s, HEADS, h, w, int(clip_frames),
-                 int(bool(attn_diff)), stream_ptr())
+            call("maavss_vit_attn_maps_checked", ptr(att), ptr(out[s:e]), ptr(ws), e - s, HEADS, h, w, int(clip_frames),
+                 int(bool(attn_diff)), ptr(flag), stream_ptr())
+        if flag is not None:
+            self._flag_host.copy_(flag, non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
+            if finite_check == "sync":
+                self.check_finite()
         return out
 
     def _inference(self, frames):

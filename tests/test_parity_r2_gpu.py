@@ -15,15 +15,25 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-# The 16-bit path rounds conv operands (forward: IEEE half, backward: bf16).  Tolerances are DERIVED FROM OPERAND ROUNDING by
-# running the oracle twin with the same operands rounded at the same points (oracle/avse_ref_cpu.py, emulate_16bit=True):
-# its distance to the pinned fp32 oracle IS the effect of the rounding -- 4-7 % relative L2 on the first conv layers'
-# gradients (they sum 1e6 products that cancel heavily, while rounding noise adds up), < 1 % from the 4th layer on.  The HIP
-# path must sit inside that envelope on both sides: within 0.5x..1.5x of it from the fp32 oracle, and closer to the emulating
-# twin than the fp32 oracle is (it follows the same rounding; BatchNorm-backward cancellation decorrelates individual
-# roundings, so the match to the emulation is not element-exact: measured 2-3 % L2 where the envelope is 6 %).
+# The 16-bit path rounds conv operands (forward: IEEE half, backward: bf16).  What that does to the GRADIENTS was measured on the
+# CPU oracle one rounding at a time (scripts/grad_rounding_ablation.py -> profiles/r3_grad_rounding_ablation.txt):
+#   * the bf16 backward operands move the gradient tensors by 0.3-0.6 % relative L2 (1 % on one BatchNorm bias at the benched shape);
+#   * the IEEE-half FORWARD operands move them by 7-8 % on the first conv layers (8-11 % on visual_encoder.1.bias; the HIP path
+#     logged 8-17 % in round 2), bf16 forward operands by 28 %, a 16-bit mantissa by 1 %: error ~ sqrt(perturbation).  The encoder
+#     gradients of these seeded-random problems are sums of ~1e6 cancelling contributions routed by MaxPool argmax / LeakyReLU
+#     sign; a forward perturbation eps re-routes a fraction ~eps of them.  It is a property of the test problem's conditioning
+#     (the exact-f32 HIP path, 3e-6 forward distance, already sits 2-3e-3 from the oracle), not of a kernel, and splitting dy
+#     into bf16 hi + lo in the first layers' weight gradients changes nothing: 7.22 % -> 7.23 %.
+# Two computations that round at the same points also decorrelate layer by layer (a value next to a rounding boundary flips;
+# scripts/fwd_stage_diff.py: 2e-7 after conv0, 3e-4 after conv4), so the emulating twin is matched within a fraction of that
+# envelope, not element-exactly.  The gates below therefore are: (1) an ABSOLUTE cap on every gradient tensor against the fp32
+# oracle at ~2x the measured forward-rounding floor, plus direction (cosine); (2) not farther from the emulating
+# twin than that twin is from fp32; (3) the forward outputs, absolutely (mask-MSE 1e-5, loss).  What training sees over several
+# steps is gated by tests/test_parity_r3_gpu.py (10-step trajectory against the fp32 twin).
 EMU_SAMPLE_TOL = 0.12      # |g - g_emulated| <= tol * (|g_emulated| + rms(g_emulated)) for every sampled element
 EMU_L2_TOL = 0.05          # relative L2 distance of each gradient tensor to the emulating oracle
+FP32_L2_CAP = 0.25         # relative L2 distance of ANY gradient tensor to the fp32 oracle (forward-rounding floor: 0.08-0.12 on the CPU)
+FP32_COS_MIN = 0.97        # and its direction
 
 
 def _build(batch, frames, width, fft_len, seed, precise, spatial_match):
@@ -41,7 +51,7 @@ def _build(batch, frames, width, fft_len, seed, precise, spatial_match):
 
 def _grad_report(model, twin_emu, twin_f32, tag):
     emu, f32 = dict(twin_emu.named_parameters()), dict(twin_f32.named_parameters())
-    worst_s, worst_l2, worst_q = 0.0, 0.0, 0.0
+    worst_s, worst_l2, worst_q, worst_cos = 0.0, 0.0, 0.0, 1.0
     for k, p in model.named_parameters():
         if k.startswith("stft_autoencoder.") or f32[k].grad is None:
             continue
@@ -59,8 +69,11 @@ def _grad_report(model, twin_emu, twin_f32, tag):
         assert l2 <= max(EMU_L2_TOL, 1.25 * env), (tag, k, "L2 vs emulating oracle", l2, env)
         assert rel <= max(EMU_SAMPLE_TOL, 3.5 * env), (tag, k, "sampled element vs emulating oracle", rel, env)   # max of 256 samples ~ 3 sigma
         assert quant <= 1.5 * env + 2e-3, (tag, k, "L2 vs fp32 oracle outside the operand-rounding envelope", quant, env)
+        cos = torch.dot(g.double(), gf.double()).item() / (g.double().norm().item() * gf.double().norm().item() + 1e-300)
+        worst_cos = min(worst_cos, cos)
+        assert quant <= FP32_L2_CAP and cos >= FP32_COS_MIN, (tag, k, "absolute gate vs the fp32 oracle", quant, cos)
     print(f"[parity] {tag}: gradients vs 16-bit-emulating oracle: worst tensor L2 {worst_l2:.2e}, worst sampled element "
-          f"{worst_s:.2e} of (|g|+rms); vs fp32 oracle (= quantisation error of bf16 backward operands): worst tensor L2 {worst_q:.2e}")
+          f"{worst_s:.2e} of (|g|+rms); vs fp32 oracle (= the IEEE-half forward operands re-routing cancelling contributions): worst tensor L2 {worst_q:.2e}, worst cosine {worst_cos:.4f}")
 
 
 @pytest.mark.parametrize("tag,batch,frames,width,spatial", [("benched T=16 224^2 adaptive", 2, 16, 224, "adaptive"),

@@ -390,3 +390,37 @@ def test_video_attention_matches_oracle(width, frames, act):
     print(f"[parity] ViT {act} {width}^2 vs fp32 oracle: max {(got - want).abs().max().item():.3e} mean {(got - want).abs().mean().item():.3e}")
     assert (got - want).abs().max().item() < mx
     assert (got - want).abs().mean().item() < mean
+
+
+def test_half_storage_overflow_is_detected_and_bf16_survives():
+    """VERDICT r2 item 4 / ADVICE r2: the extractor stores activations as IEEE half by default (the reference computes in fp32,
+    video_attention.py:52).  mlp.fc1 of block 0 scaled so that the GELU hidden exceeds 65504: the half extractor must raise
+    (naming act_dtype='bf16'), in the synchronous and in the deferred form; the bf16 extractor must produce finite maps."""
+    import maavss_amd
+    from maavss_amd._lib import MaavssError
+    from oracle import vit_ref_cpu as vref
+    sd = vref.seeded_vit_state(3)
+    sd["blocks.0.mlp.fc1.weight"] = sd["blocks.0.mlp.fc1.weight"] * 3e5
+    fr = vref.synthetic_frames(4, 64, 5).cuda()
+    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype="f16")
+    va.load_state_dict(sd)
+    with pytest.raises(MaavssError, match="bf16"):
+        va.attention_frames(fr, clip_frames=4)
+    # deferred: the call itself returns (no host-device synchronisation), the flag surfaces at the next call / check_finite()
+    va.attention_frames(fr, clip_frames=4, finite_check="deferred")
+    with pytest.raises(MaavssError, match="bf16"):
+        va.check_finite()
+    va.attention_frames(fr, clip_frames=4, finite_check="deferred")
+    with pytest.raises(MaavssError, match="65504"):
+        va.attention_frames(fr, clip_frames=4, finite_check="deferred")
+    out = va.attention_frames(fr, clip_frames=4, finite_check=None)          # unchecked: the NaNs are there
+    assert not torch.isfinite(out).all()
+    with pytest.raises(MaavssError):
+        va._inference(fr.cpu())                                                # the reference entry point checks synchronously
+    vb = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype="bf16")
+    vb.load_state_dict(sd)
+    out = vb.attention_frames(fr, clip_frames=4)
+    assert torch.isfinite(out).all() and out.max().item() == pytest.approx(1.0, abs=1e-6)
+    # and an in-range checkpoint passes the check untouched
+    va.load_state_dict(vref.seeded_vit_state(3))
+    assert torch.isfinite(va.attention_frames(fr, clip_frames=4)).all()
