@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true", help="global-batch BatchNorm statistics over the ranks (N > 1)")
     ap.add_argument("--attn-dtype", choices=["same", "fp8"], default="same",
                     help="fp8: Q K^T / P V of the ViT blocks on fp8 (e4m3) MFMA (BASELINE config 'fp8 MFMA attention'); the headline line uses 'same'")
+    ap.add_argument("--pipeline", choices=["on", "off"], default="on",
+                    help="on: attention-frame extraction + STFT of batch i+1 on a second HIP stream under the training step of batch i "
+                         "(maavss_amd.ClipPipeline; the reference's data path has no dependency on the optimizer step); off: one stream")
     ap.add_argument("--vit-dtype", choices=["f16", "bf16"], default="f16",
                     help="16-bit storage / MFMA operand format of the ViT extractor (same MFMA rate; f16 meets the 1e-5 mask-MSE end to end)")
     return ap.parse_args()
@@ -182,18 +185,31 @@ def main():
     mid = t // 2
     attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
 
+    pipe = maavss_amd.ClipPipeline(va, stft, t) if args.pipeline == "on" else None
+
     def step(i):
-        va.attention_frames(frames, clip_frames=t, out=attn, finite_check="deferred")   # range guard of the half storage, no sync
-        x_v = attn.view(b, 1, t, w, w)
-        x_stft, y_stft = stft(audio, seed=i)
+        """One batch through the whole hot path.  Pipelined form: every call enqueues exactly one extraction (batch i+1, side
+        stream) and one training step (batch i, extracted by the previous call) -- the same work per step as the serial form."""
+        if pipe is None:
+            va.attention_frames(frames, clip_frames=t, out=attn, finite_check="deferred")   # range guard of the half storage, no sync
+            x_v = attn.view(b, 1, t, w, w)
+            x_stft, y_stft = stft(audio, seed=i)
+        else:
+            if pipe.head == pipe.tail:
+                pipe.submit(frames, audio, seed=i)          # first call only: fill the pipeline
+            pipe.submit(frames, audio, seed=i + 1)
+            x_v, x_stft, y_stft = pipe.get()
         y_a = y_stft[:, :, mid * hpf:(mid + 1) * hpf, :]
         y_v = x_v[:, :, mid]
-        return step_fn(x_stft, x_v, y_a, y_v)
+        out = step_fn(x_stft, x_v, y_a, y_v)
+        if pipe is not None:
+            pipe.release()
+        return out
 
     def sync_all():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()             # all streams of the device, the pipeline's side stream included
 
     for i in range(args.warmup):
         step(i)
@@ -221,7 +237,9 @@ def main():
         step(args.warmup + args.steps + i)
     sync_all()
     elapsed_plain = time.perf_counter() - t1
-    va.check_finite()                        # the last step's deferred range flag
+    if pipe is not None:
+        pipe.drain()
+    va.check_finite()                        # the deferred range flags of the last steps
 
     if rank == 0:
         summ = timer.summary()
@@ -363,7 +381,7 @@ def main():
             "config": {"workload": f"batch={b}/GPU, {t} frames {w}x{w}, {args.fft_len}-pt STFT, ViT-S/8 attention extraction "
                                    f"({args.vit_dtype} MFMA operands, f32 accumulate) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
-                       "parallelism": f"dp{world}", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
+                       "parallelism": f"dp{world}", "streams": "2 (extraction of batch i+1 under the training step of batch i)" if pipe is not None else "1", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
                        "vit": args.vit_dtype, "vit_attention": "fp8 e4m3" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
                        "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank",
                        "loss": loss_val},

@@ -11,4 +11,5 @@ from .phasegram import video_phasegram  # noqa: F401
 from .trainer import FusedAdam, GradSync, TrainStep, shard_batch  # noqa: F401
 from .video_attention import VideoAttention  # noqa: F401
 from .checkpoint import latest_file, load_checkpoint, save_checkpoint, save_model  # noqa: F401
+from .pipeline import ClipPipeline  # noqa: F401
 from . import attn_cache  # noqa: F401

@@ -543,11 +543,13 @@ class AV_Fusion_Model_Frames(nn.Module):
         v_out = v.view(b, self.frame_channels, w, w)
         return (a_out, v_out, fused), sv
 
-    def _engine_backward(self, sv, d_a, d_v, d_fused, need, grads=None, accumulate=False, on_fusion_done=None):
+    def _engine_backward(self, sv, d_a, d_v, d_fused, need, grads=None, accumulate=False, on_fusion_done=None, on_grad=None):
         """Hand-written backward.  `need[name]` says which parameter gradients are wanted; results go into
         `grads[name]` (pre-allocated when `grads` is given -- e.g. views of a flat gradient buffer --,
         `accumulate` then adds instead of overwriting).  `on_fusion_done` is called once the gradients of the
-        LSTM / fc / head weights (98 % of the bytes) are complete, so their all-reduce can overlap the rest."""
+        LSTM / fc / head weights (98 % of the bytes) are complete, so their all-reduce can overlap the rest; `on_grad(name)`
+        after each of those weight gradients has been enqueued (trainer.GradSync launches its buckets from it: the heads'
+        all-reduce starts while fc2 / fc1 / the LSTM are still in their backward pass)."""
         # conv backward operands: bf16 (gradients need the exponent range), or exact f32; Linear layers always f32
         pr_conv, pr = (ops.MODE_F32 if self.precise else ops.MODE_BF16), ops.MODE_F32
         out_grads = {}
@@ -565,6 +567,8 @@ class AV_Fusion_Model_Frames(nn.Module):
             buf, beta = gbuf(name)
             ops.gemm(dz, x, trans_a=True, trans_b=True, out=buf, beta=beta, precise=pr)
             out_grads[name] = buf
+            if on_grad is not None:
+                on_grad(name)
 
         b, l, t = sv["x_v"].shape[0], self.latent_channels, self.t_v
         ts = t * self.s_v

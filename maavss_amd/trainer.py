@@ -113,7 +113,8 @@ class FusedAdam:
         self.steps = {k: int(n) for k in self.steps}
 
     def _runs(self):
-        """[(lo, hi, step)] maximal runs of touched parameters with equal step counts, in buffer order."""
+        """[(lo, hi, step, names)]: maximal runs of touched parameters with equal step counts, in buffer order.  Pure planning:
+        the per-parameter step counts are committed by step() once the launches are issued."""
         f, runs = self.flat, []
         for n in f.names:
             if n not in f.touched or not f.tensors[n].requires_grad:
@@ -125,17 +126,24 @@ class FusedAdam:
             hi = _align(lo + k)
             if runs and runs[-1][1] == lo and runs[-1][2] == st:
                 runs[-1][1] = hi
+                runs[-1][3].append(n)
             else:
-                runs.append([lo, hi, st])
-            self.steps[n] = st
-        return runs
+                runs.append([lo, hi, st, [n]])
+        return [tuple(r) for r in runs]
+
+    def _commit(self, runs):
+        for _, _, st, names in runs:
+            for n in names:
+                self.steps[n] = st
 
     def step(self, grad_scale=1.0):
         self.flat.check_links()
-        for lo, hi, st in self._runs():
+        runs = self._runs()
+        for lo, hi, st, _ in runs:
             hi = min(hi, self.flat.total)
             ops.adam_step(self.flat.params[lo:hi], self.flat.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                           self.lr, st, self.betas, self.eps, grad_scale)
+        self._commit(runs)
 
     def zero_grad(self, set_to_none=False):
         """memset of the flat gradient buffer; the views stay attached to p.grad whatever `set_to_none` says (gradients
@@ -193,18 +201,46 @@ class FusedAdam:
 class GradSync:
     """Sum-all-reduce of the flat gradient buffer across data-parallel ranks (K18).
 
-    Works on any torch.distributed backend ("nccl" = RCCL on ROCm for the GPUs, "gloo" in CPU tests).
-    `start_fusion()` launches the large segment asynchronously as soon as its gradients exist;
-    `finish()` reduces the encoder segment and waits for both.  With world_size 1 it is a no-op."""
+    Works on any torch.distributed backend ("nccl" = RCCL on ROCm for the GPUs, "gloo" in CPU tests); with world_size 1
+    every method is a no-op.  The buffer is reduced in BUCKETS, in the order the backward pass completes them
+    ("bucketed in reverse-layer order to overlap with conv3d backward"): with a FlatParams layout the fusion
+    segment is one bucket per top-level module -- heads (a_fc1, v_fc1), fc2, fc1, lstm -- each launched asynchronously by
+    `grad_ready(name)` the moment its last gradient has been enqueued, so the first all-reduce (the 26 M-float v_fc1 head)
+    starts after the heads' weight gradients, not after the whole fusion segment; the encoder segment follows in `finish()`,
+    which also waits for everything.  Only parameters that receive a gradient this step take part (`begin(expected)`, the
+    same set on every rank): a bucket without any is skipped, stale regions inside a reduced bucket are zeroed first -- a
+    frozen parameter's old gradient is never summed over the ranks step after step.
+    `start_fusion()` (round-1/2 interface) launches whatever is left of the fusion segment in one go."""
 
-    def __init__(self, grads, fusion_end, process_group=None):
+    def __init__(self, grads, fusion_end, process_group=None, flat=None):
         import torch.distributed as dist
         self.dist = dist
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.group = process_group
         self.grads, self.fusion_end = grads, fusion_end
-        self._pending = None
+        # buckets: [lo, hi) of the flat buffer + the (name, lo, hi) of the parameters inside, fusion segment first
+        self.buckets = []
+        if flat is not None:
+            for n in flat.names:
+                lo = flat.offsets[n]
+                k = 1
+                for d in flat.shapes[n]:
+                    k *= d
+                hi = _align(lo + k)
+                key = "encoders" if lo >= fusion_end else n.split(".")[0]
+                if self.buckets and self.buckets[-1]["key"] == key:
+                    self.buckets[-1]["hi"] = hi
+                    self.buckets[-1]["params"].append((n, lo, hi))
+                else:
+                    self.buckets.append(dict(key=key, lo=lo, hi=hi, params=[(n, lo, hi)]))
+            self.buckets[-1]["hi"] = min(self.buckets[-1]["hi"], grads.numel())
+        else:
+            self.buckets = [dict(key="fusion", lo=0, hi=fusion_end, params=[]),
+                            dict(key="encoders", lo=fusion_end, hi=grads.numel(), params=[])]
+        self._bucket_of = {n: i for i, b in enumerate(self.buckets) for n, _, _ in b["params"]}
+        self._expected, self._ready, self._launched, self._pending = None, set(), set(), []
+        self.launch_log = []          # keys of the buckets in launch order, per step (tests, tracing)
 
     def broadcast(self, tensors, src=0):
         """Make the replicas identical: rank `src`'s values everywhere (parameters, BatchNorm buffers), as DDP does at
@@ -219,21 +255,57 @@ class GradSync:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def begin(self, expected=None):
+        """Start of a backward pass whose gradients will be reduced: `expected` = names that will receive a gradient
+        (None = every parameter).  Must be the same on every rank (it follows requires_grad, which is)."""
+        self._expected = None if expected is None else set(expected)
+        self._ready, self._launched, self._pending, self.launch_log = set(), set(), [], []
+
+    def _wanted(self, b):
+        return [p for p in b["params"] if self._expected is None or p[0] in self._expected]
+
+    def _launch(self, i):
+        if i in self._launched:
+            return
+        self._launched.add(i)
+        b = self.buckets[i]
+        if not self.enabled or b["hi"] <= b["lo"]:
+            return
+        if b["params"]:
+            wanted = self._wanted(b)
+            if not wanted:
+                return                                   # nothing in this bucket received a gradient: not reduced at all
+            if len(wanted) < len(b["params"]):
+                keep = {p[0] for p in wanted}
+                for n, lo, hi in b["params"]:
+                    if n not in keep:
+                        self.grads[lo:min(hi, b["hi"])].zero_()      # stale gradient of a frozen parameter
+        self.launch_log.append(b["key"])
+        self._pending.append(self.dist.all_reduce(self.grads[b["lo"]:b["hi"]], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+
+    def grad_ready(self, name):
+        """The gradient of `name` has been enqueued on the current stream; launches its bucket when that completes it."""
+        i = self._bucket_of.get(name)
+        if i is None or self.buckets[i]["key"] == "encoders":
+            return
+        self._ready.add(name)
+        if all(p[0] in self._ready for p in self._wanted(self.buckets[i])):
+            self._launch(i)
+
     def start_fusion(self):
-        if self.enabled:
-            self._pending = self.dist.all_reduce(self.grads[:self.fusion_end], op=self.dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True)
+        for i, b in enumerate(self.buckets):
+            if b["key"] != "encoders":
+                self._launch(i)
 
     def finish(self):
-        if not self.enabled:
-            return
-        if self._pending is None:
-            self.start_fusion()
-        tail = self.dist.all_reduce(self.grads[self.fusion_end:], op=self.dist.ReduceOp.SUM, group=self.group,
-                                    async_op=True)
-        self._pending.wait()
-        tail.wait()
-        self._pending = None
+        self.start_fusion()
+        for i, b in enumerate(self.buckets):
+            self._launch(i)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._expected, self._ready, self._launched = None, set(), set()
 
 
 def shard_batch(global_batch, rank, world):
@@ -252,7 +324,7 @@ class TrainStep:
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.loss_coeff, self.num_seq = loss_coeff, num_seq
-        self.sync = GradSync(self.flat.grads, self.flat.fusion_end, process_group)
+        self.sync = GradSync(self.flat.grads, self.flat.fusion_end, process_group, flat=self.flat)
         # replicas start identical: rank 0's weights (one flat buffer) and BatchNorm buffers, like DDP's constructor
         self.sync.broadcast([self.flat.params] + [b for _, b in model.named_buffers()])
         if sync_bn and self.sync.enabled:
@@ -271,8 +343,11 @@ class TrainStep:
         (a, v, fused), sv = m._engine_forward(x_a, x_v, train=True)
         self.outputs = (a, v, fused)
         self.losses, d_a, d_v = ops.mse_pair(a, y_a.contiguous(), v, y_v.contiguous(), self.loss_coeff, self.num_seq)
+        if last:
+            self.sync.begin(n for n in m._param_names if need.get(n, False))
         out = m._engine_backward(sv, d_a, d_v, None, need, grads=self.flat.grad_views, accumulate=accumulate,
-                                 on_fusion_done=self.sync.start_fusion if last else None)
+                                 on_fusion_done=self.sync.start_fusion if last else None,
+                                 on_grad=self.sync.grad_ready if last else None)
         self.flat.mark(out.keys())
         if last:
             self.sync.finish()

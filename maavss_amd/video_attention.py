@@ -130,7 +130,7 @@ class VideoAttention:
         self._dev = None          # device-side weight images, built lazily
         self._tables = {}
         # range guard of the 16-bit storage (see attention_frames): sticky device flag + the pinned host copy of the last call
-        self._flag = self._flag_host = self._flag_event = None
+        self._flag, self._flag_pending, self._flag_hosts = None, [], []
 
     def __load_model(self, pretrained_weights):
         model = ViTSmall8Weights()
@@ -260,16 +260,20 @@ class VideoAttention:
         call("maavss_vit_cls_attn", ptr(qkv), ptr(att), f, ntok, HEADS, 3 * DIM, dt, st)
         return att
 
-    def check_finite(self):
-        """Raise if a previous attention_frames(..., finite_check="deferred") call produced a non-finite CLS attention
-        (waits for that call's flag copy only, not for the device)."""
-        if self._flag_event is None:
-            return
-        self._flag_event.synchronize()
-        self._flag_event = None
-        if int(self._flag_host.item()) != 0:
+    def check_finite(self, wait=True):
+        """Raise if an attention_frames(..., finite_check="deferred") call produced a non-finite CLS attention.  wait=True waits for
+        the flag copies of all such calls (not for the device); wait=False looks only at copies that have already arrived."""
+        raised = False
+        while self._flag_pending:
+            event, host = self._flag_pending[0]
+            if not wait and not event.query():
+                break
+            event.synchronize()
+            self._flag_pending.pop(0)
+            raised |= int(host.item()) != 0
+        if raised:
+            self._flag_pending.clear()
             self._flag.zero_()
-            self._flag_host.zero_()
             raise _lib.MaavssError(
                 "VideoAttention: non-finite attention maps -- an activation of the ViT left the range of its 16-bit storage "
                 f"format (act_dtype={self.act_dtype!r}" + (": IEEE half saturates at 65504; build the extractor with "
@@ -286,15 +290,15 @@ class VideoAttention:
         finite_check: the reference runs the ViT in fp32; here activations are stored in 16 bits and IEEE half (the default)
         overflows above 65504 -> inf -> NaN maps.  The maps kernel raises a sticky device flag when a CLS-attention value is
         not finite (every upstream overflow ends there).  "sync" (default): wait for this call and raise MaavssError now;
-        "deferred": copy the flag to pinned host memory asynchronously and raise at the NEXT call / check_finite() -- no
-        host-device synchronisation inside a training step (bench.py); None: no check."""
+        "deferred": copy the flag to pinned host memory asynchronously and raise at a later call (once the copy has arrived)
+        or at check_finite() -- no host-device synchronisation inside a training step (bench.py); None: no check."""
         _lib.require_cuda(frames)
         if finite_check not in ("sync", "deferred", None):
             raise ValueError("finite_check must be 'sync', 'deferred' or None")
-        self.check_finite()                       # a deferred flag of the previous call
+        self.check_finite(wait=False)             # deferred flags of earlier calls that have arrived (never blocks)
         if finite_check is not None and self._flag is None:
             self._flag = torch.zeros(1, device=self.device, dtype=torch.int32)
-            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_hosts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(8)]
         flag = self._flag if finite_check is not None else None
         f, _, h, w = frames.shape
         if out is None:
@@ -310,9 +314,14 @@ class VideoAttention:
             call("maavss_vit_attn_maps_checked", ptr(att), ptr(out[s:e]), ptr(ws), e - s, HEADS, h, w, int(clip_frames),
                  int(bool(attn_diff)), ptr(flag), stream_ptr())
         if flag is not None:
-            self._flag_host.copy_(flag, non_blocking=True)
-            self._flag_event = torch.cuda.Event()
-            self._flag_event.record()
+            if len(self._flag_pending) >= len(self._flag_hosts):
+                self.check_finite()               # the ring of pinned flag copies is full: wait for the oldest calls
+            used = {id(h) for _, h in self._flag_pending}
+            host = next(h for h in self._flag_hosts if id(h) not in used)
+            host.copy_(flag, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            self._flag_pending.append((event, host))
             if finite_check == "sync":
                 self.check_finite()
         return out

@@ -23,12 +23,14 @@ def test_adam_runs_cover_exactly_the_touched_parameters():
     assert opt._runs() == []                                       # nothing received a gradient yet
     f.mark(model._param_names)                                     # what forward()'s backward produces
     runs = opt._runs()
-    covered = sum(hi - lo for lo, hi, _ in runs)
+    assert opt._runs() == runs and all(v == 0 for v in opt.steps.values())      # planning is pure: nothing committed yet
+    opt._commit(runs)
+    covered = sum(hi - lo for lo, hi, _, _ in runs)
     want = sum((_numel(f.shapes[n]) + 63) // 64 * 64 for n in model._param_names)
-    assert covered == want and all(st == 1 for _, _, st in runs)
+    assert covered == want and all(st == 1 for _, _, st, _ in runs)
     # stft_decoder.* (no gradient under forward(), avse_model_final.py:258-274) is outside every run
     for n in f.names:
-        inside = any(lo <= f.offsets[n] < hi for lo, hi, _ in runs)
+        inside = any(lo <= f.offsets[n] < hi for lo, hi, _, _ in runs)
         assert inside == (not n.startswith("stft_decoder.")), n
     sd = opt.state_dict()
     stepped = {f.torch_order[i] for i in sd["state"]}
@@ -40,23 +42,24 @@ def test_adam_runs_cover_exactly_the_touched_parameters():
     model.toggle_enc_grads(False)
     f.mark(model._param_names)
     runs = opt._runs()
+    opt._commit(runs)
     for n in f.names:
-        inside = any(lo <= f.offsets[n] < hi for lo, hi, _ in runs)
+        inside = any(lo <= f.offsets[n] < hi for lo, hi, _, _ in runs)
         frozen = n.startswith("visual_encoder.") or n.startswith("stft_encoder.") or n.startswith("stft_decoder.")
         assert inside == (not frozen), n
     assert opt.steps["fc1.weight"] == 2 and opt.steps["visual_encoder.0.weight"] == 1
     # runs with different step counts are never merged
-    assert len({st for _, _, st in runs}) == 1
+    assert len({st for _, _, st, _ in runs}) == 1
 
 
 def test_state_dict_round_trip_keeps_per_parameter_steps():
     model = maavss_amd.AV_Fusion_Model_Frames(*SHAPES)
     opt = FusedAdam(model, lr=2e-4)
     opt.flat.mark(["fc1.weight", "fc2.weight"])
-    opt._runs()
-    opt._runs()
+    opt._commit(opt._runs())
+    opt._commit(opt._runs())
     opt.flat.mark(["a_fc1.0.weight"])
-    opt._runs()
+    opt._commit(opt._runs())
     sd = opt.state_dict()
     opt2 = FusedAdam(maavss_amd.AV_Fusion_Model_Frames(*SHAPES), lr=1.0)
     opt2.load_state_dict(sd)

@@ -411,6 +411,7 @@ def test_half_storage_overflow_is_detected_and_bf16_survives():
     with pytest.raises(MaavssError, match="bf16"):
         va.check_finite()
     va.attention_frames(fr, clip_frames=4, finite_check="deferred")
+    torch.cuda.synchronize()                                                   # the flag copy has arrived: the next call sees it without waiting
     with pytest.raises(MaavssError, match="65504"):
         va.attention_frames(fr, clip_frames=4, finite_check="deferred")
     out = va.attention_frames(fr, clip_frames=4, finite_check=None)          # unchecked: the NaNs are there
