@@ -15,6 +15,7 @@ returned frames and is not computed.
 """
 import math
 import os
+import sys
 
 import torch
 
@@ -143,7 +144,7 @@ class VideoAttention:
             model.loaded_from = pretrained_weights
         else:
             print(f"[maavss_amd] DINO weights '{pretrained_weights}' not found and there is no network: "
-                  f"VideoAttention keeps its random initialisation (load one with .model.load_state_dict).")
+                  f"VideoAttention keeps its random initialisation (load one with .model.load_state_dict).", file=sys.stderr)
         return model
 
     def load_state_dict(self, sd, strict=True):
