@@ -186,19 +186,10 @@ def main():
     attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
 
     pipe = maavss_amd.ClipPipeline(va, stft, t) if args.pipeline == "on" else None
-    # measurement knob (scripts/pipe_chunk_sweep.sh): the training step on a high-priority HIP stream next to the extractor
-    train_stream = torch.cuda.Stream(priority=-1) if (pipe is not None and os.environ.get("MAAVSS_BENCH_TRAIN_PRIORITY") == "high") else None
 
     def step(i, serial=False):
         """One batch through the whole hot path.  Pipelined form: every call enqueues exactly one extraction (batch i+1, side
         stream) and one training step (batch i, extracted by the previous call) -- the same work per step as the serial form."""
-        if train_stream is not None and not serial:
-            train_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(train_stream):
-                return step_body(i, serial)
-        return step_body(i, serial)
-
-    def step_body(i, serial):
         if pipe is None or serial:
             va.attention_frames(frames, clip_frames=t, out=attn, finite_check="deferred")   # range guard of the half storage, no sync
             x_v = attn.view(b, 1, t, w, w)

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from .avse import _bn_eval_reduce
 
 FUSED_DIM, LSTM_HIDDEN, SLOPE = 512, 256, 0.3
 
@@ -93,17 +94,59 @@ class _Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         model = ctx.model
-        if not ctx.was_training:
-            raise _lib.MaavssError("backward through an eval-mode forward (running-statistics BatchNorm) is not built; "
-                                   "call model.train() for training steps")
         names = model._names[ctx.mode]
         need = {n: ctx.needs_input_grad[2 + ctx.n_in + i] for i, n in enumerate(names)}
-        grads = model._run_backward(ctx.mode, ctx.saved, d_outs, need)
+        model._bn_eval = not ctx.was_training       # eval-mode forward: BatchNorm backward without the batch-mean terms
+        try:
+            grads = model._run_backward(ctx.mode, ctx.saved, d_outs, need)
+        finally:
+            model._bn_eval = False
         ctx.saved = None
         flat = getattr(model, "_maavss_flat", None)
         if flat is not None:      # FusedAdam steps only parameters that received a gradient (torch.optim.Adam semantics)
             flat.mark(n for n in names if grads.get(n) is not None)
         return (None, None) + (None,) * ctx.n_in + tuple(grads.get(n) for n in names)
+
+
+_FUSION_PARAMS = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.weight_ih_l0_reverse", "lstm.weight_hh_l0_reverse",
+                  "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+
+
+class _FusionFn(torch.autograd.Function):
+    """av_fusion_forward (avse_model.py:658-670) from given encodings, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, model, x_a, x_v, *params):
+        b, h, w = x_a.shape[0], model.h, model.w_enc
+        cv, ca = model.c_v, model.c_a
+        # permute(0, 2, 1, 3) + cat(dim=2) + flatten == two strided device copies into the LSTM sequence buffer
+        seq = torch.empty(b, h, (cv + ca) * w, device=x_a.device, dtype=torch.float32)
+        seq[:, :, :cv * w].view(b, h, cv, w).copy_(x_v.permute(0, 2, 1, 3))
+        seq[:, :, cv * w:].view(b, h, ca, w).copy_(x_a.permute(0, 2, 1, 3))
+        sv = {}
+        fused = model._fusion_fwd(seq, sv)
+        ctx.model, ctx.saved = model, sv
+        return fused
+
+    @staticmethod
+    def backward(ctx, d_fused):
+        model, sv = ctx.model, ctx.saved
+        need = {n: ctx.needs_input_grad[3 + i] for i, n in enumerate(_FUSION_PARAMS)}
+        grads = {}
+        dgx = model._fusion_bwd(sv, d_fused.contiguous().float(), need, grads)
+        d_a = d_v = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            b, h, w, cv, ca = sv["seq"].shape[0], model.h, model.w_enc, model.c_v, model.c_a
+            dseq = model._fusion_dseq(dgx).view(b, h, (cv + ca) * w)
+            if ctx.needs_input_grad[2]:
+                d_v = dseq[:, :, :cv * w].reshape(b, h, cv, w).permute(0, 2, 1, 3)
+            if ctx.needs_input_grad[1]:
+                d_a = dseq[:, :, cv * w:].reshape(b, h, ca, w).permute(0, 2, 1, 3)
+        ctx.saved = None
+        flat = getattr(model, "_maavss_flat", None)
+        if flat is not None:
+            flat.mark(n for n in _FUSION_PARAMS if grads.get(n) is not None)
+        return (None, d_a, d_v) + tuple(grads.get(n) for n in _FUSION_PARAMS)
 
 
 class AV_Fusion_Model(nn.Module):
@@ -201,8 +244,17 @@ class AV_Fusion_Model(nn.Module):
     def audio_ae_forward(self, x_a):
         return self._engine("audio_ae", x_a)
 
-    def av_fusion_forward(self, x_a_enc, x_v_enc):
-        raise NotImplementedError("call forward(); the fused engine does not expose the intermediate encodings")
+    def av_fusion_forward(self, x_a, x_v):
+        """avse_model.py:658-670: encodings x_a [B, c_a, h, w], x_v [B, c_v, h, w] -> x_av_fused [B, 512] (permute to rows,
+        cat on the channel dim, flatten, BiLSTM over the h rows, fc1, LeakyReLU(0.3), fc2, LeakyReLU(0.3)) as one autograd
+        node over the HIP engine; differentiable in both encodings and the LSTM / fc weights and biases."""
+        _lib.require_cuda(x_a, x_v)
+        want_a, want_v = (self.c_a, self.h, self.w_enc), (self.c_v, self.h, self.w_enc)
+        if tuple(x_a.shape[1:]) != want_a or tuple(x_v.shape[1:]) != want_v or x_a.shape[0] != x_v.shape[0]:
+            raise ValueError(f"av_fusion_forward expects encodings [B, {want_a[0]}, {want_a[1]}, {want_a[2]}] (audio) and "
+                             f"[B, {want_v[0]}, {want_v[1]}, {want_v[2]}] (phasegram), got {tuple(x_a.shape)} and {tuple(x_v.shape)}")
+        pd = dict(self.named_parameters())
+        return _FusionFn.apply(self, x_a, x_v, *[pd[n] for n in _FUSION_PARAMS])
 
     # ---- engine: convolution stacks ---------------------------------------------------------------------------
     def _mods(self, layer):
@@ -303,7 +355,8 @@ class AV_Fusion_Model(nn.Module):
                 else:
                     dout, out = dcur.view(s["y5"].shape), s["out"]
                 dy = ops.bn_pool_act_bwd(dout, out, None, s["y5"], s["mean"], s["invstd"], s["gamma"], 1, ops.BN_TANH,
-                                         strides=s["strides"], dgamma=gw, dbeta=gb)
+                                         strides=s["strides"], dgamma=gw, dbeta=gb,
+                                         reduce_fn=_bn_eval_reduce if getattr(self, "_bn_eval", False) else None)
                 if need.get(f"{prefix}.{idx + 1}.weight", False):
                     grads[f"{prefix}.{idx + 1}.weight"] = gw[:ymap.c].clone()
                 if need.get(f"{prefix}.{idx + 1}.bias", False):
@@ -354,17 +407,60 @@ class AV_Fusion_Model(nn.Module):
         _, s_v = self._stack_forward("pgram_enc", ops.Map(x_v, nchw=True), train, seq_out=(seq, 0, strides))
         _, s_a = self._stack_forward("stft_enc", ops.Map(x_a, nchw=True), train, seq_out=(seq, self.c_v * w, strides))
         pr = ops.MODE_F32
+        saved = dict(s_v=s_v, s_a=s_a, strides=strides)
+        fused = self._fusion_fwd(seq, saved)
+        a = ops.bias_act_(ops.gemm(fused, self.a_fc1[0].weight.detach(), precise=pr), self.a_fc1[0].bias.detach(), ops.ACT_LEAKY, SLOPE)
+        v = ops.bias_act_(ops.gemm(fused, self.v_fc1[0].weight.detach(), precise=pr), self.v_fc1[0].bias.detach(), ops.ACT_LEAKY, SLOPE)
+        saved.update(a=a, v=v)
+        return (a.view(x_a.shape), v.view(x_v.shape), fused), saved
+
+    def _fusion_fwd(self, seq, sv):
+        """av_fusion_forward (avse_model.py:658-670) on the sequence buffer seq [B, h, (c_v + c_a) * w]: BiLSTM over the h
+        phasegram rows, fc1 + bias + LeakyReLU(0.3), fc2 + bias + LeakyReLU(0.3)."""
+        pr = ops.MODE_F32
+        b, h, feat = seq.shape
         seq2d = seq.view(b * h, feat)
-        gx = torch.empty(b * h, 2048, device=dev, dtype=torch.float32)
+        gx = torch.empty(b * h, 2048, device=seq.device, dtype=torch.float32)
         ops.gemm(seq2d, self.lstm.weight_ih_l0.detach(), out=gx[:, :1024], precise=pr, split_k=1)
         ops.gemm(seq2d, self.lstm.weight_ih_l0_reverse.detach(), out=gx[:, 1024:], precise=pr, split_k=1)
         av, hp, gs, cs = ops.lstm_fwd(gx.view(b, h, 2, 4, 256), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach())
         h1 = ops.bias_act_(ops.gemm(av.view(b, h * 512), self.fc1.weight.detach(), precise=pr), self.fc1.bias.detach(), ops.ACT_LEAKY, SLOPE)
         fused = ops.bias_act_(ops.gemm(h1, self.fc2.weight.detach(), precise=pr), self.fc2.bias.detach(), ops.ACT_LEAKY, SLOPE)
-        a = ops.bias_act_(ops.gemm(fused, self.a_fc1[0].weight.detach(), precise=pr), self.a_fc1[0].bias.detach(), ops.ACT_LEAKY, SLOPE)
-        v = ops.bias_act_(ops.gemm(fused, self.v_fc1[0].weight.detach(), precise=pr), self.v_fc1[0].bias.detach(), ops.ACT_LEAKY, SLOPE)
-        saved = dict(s_v=s_v, s_a=s_a, seq=seq, strides=strides, av=av, hp=hp, gs=gs, cs=cs, h1=h1, fused=fused, a=a, v=v)
-        return (a.view(x_a.shape), v.view(x_v.shape), fused), saved
+        sv.update(seq=seq, av=av, hp=hp, gs=gs, cs=cs, h1=h1, fused=fused)
+        return fused
+
+    def _fusion_bwd(self, sv, dfused, need, grads):
+        """Backward of _fusion_fwd: parameter gradients into `grads`; returns the LSTM gate gradient dgx [B*h, 2048]."""
+        pr = ops.MODE_F32
+        b, h = sv["seq"].shape[0], self.h
+        fused, h1, av = sv["fused"], sv["h1"], sv["av"]
+
+        def lin(name_w, name_b, dz, x):
+            if need.get(name_w, False):
+                grads[name_w] = ops.gemm(dz, x, trans_a=True, trans_b=True, precise=pr)
+            if need.get(name_b, False):
+                grads[name_b] = ops.rows_sum(dz)
+
+        dz2 = ops.leaky_bwd(dfused, fused, SLOPE)
+        lin("fc2.weight", "fc2.bias", dz2, h1)
+        dh1 = ops.gemm(dz2, self.fc2.weight.detach(), trans_b=True, precise=pr)
+        dz1 = ops.leaky_bwd(dh1, h1, SLOPE)
+        lin("fc1.weight", "fc1.bias", dz1, av.view(b, h * 512))
+        dav = ops.gemm(dz1, self.fc1.weight.detach(), trans_b=True, precise=pr)
+        dgx = ops.lstm_bwd(dav.view(b, h, 512), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach(),
+                           sv["gs"], sv["cs"]).view(b * h, 2048)
+        seq2d, hp2 = sv["seq"].view(b * h, -1), sv["hp"].view(b * h, 512)
+        for nm, dz, x in (("lstm.weight_ih_l0", dgx[:, :1024], seq2d), ("lstm.weight_ih_l0_reverse", dgx[:, 1024:], seq2d),
+                          ("lstm.weight_hh_l0", dgx[:, :1024], hp2[:, :256]), ("lstm.weight_hh_l0_reverse", dgx[:, 1024:], hp2[:, 256:])):
+            if need.get(nm, False):
+                grads[nm] = ops.gemm(dz, x, trans_a=True, trans_b=True, precise=pr)
+        return dgx
+
+    def _fusion_dseq(self, dgx):
+        pr = ops.MODE_F32
+        dseq = ops.gemm(dgx[:, :1024], self.lstm.weight_ih_l0.detach(), trans_b=True, precise=pr)
+        ops.gemm(dgx[:, 1024:], self.lstm.weight_ih_l0_reverse.detach(), trans_b=True, out=dseq, beta=1, precise=pr)
+        return dseq
 
     def _run_backward(self, mode, sv, d_outs, need):
         grads = {}
@@ -403,25 +499,11 @@ class AV_Fusion_Model(nn.Module):
             dfused = d_fused.contiguous().clone() if dfused is None else dfused.add_(d_fused)      # tiny [B,512] glue
         if dfused is None:
             raise _lib.MaavssError("backward called without any output gradient")
-        dz2 = ops.leaky_bwd(dfused, fused, SLOPE)
-        lin("fc2.weight", "fc2.bias", dz2, h1)
-        dh1 = ops.gemm(dz2, self.fc2.weight.detach(), trans_b=True, precise=pr)
-        dz1 = ops.leaky_bwd(dh1, h1, SLOPE)
-        avf = av.view(b, h * 512)
-        lin("fc1.weight", "fc1.bias", dz1, avf)
-        dav = ops.gemm(dz1, self.fc1.weight.detach(), trans_b=True, precise=pr)
-        dgx = ops.lstm_bwd(dav.view(b, h, 512), self.lstm.weight_hh_l0.detach(), self.lstm.weight_hh_l0_reverse.detach(),
-                           sv["gs"], sv["cs"]).view(b * h, 2048)
-        seq2d, hp2 = sv["seq"].view(b * h, -1), sv["hp"].view(b * h, 512)
-        for nm, dz, x in (("lstm.weight_ih_l0", dgx[:, :1024], seq2d), ("lstm.weight_ih_l0_reverse", dgx[:, 1024:], seq2d),
-                          ("lstm.weight_hh_l0", dgx[:, :1024], hp2[:, :256]), ("lstm.weight_hh_l0_reverse", dgx[:, 1024:], hp2[:, 256:])):
-            if need.get(nm, False):
-                grads[nm] = ops.gemm(dz, x, trans_a=True, trans_b=True, precise=pr)
+        dgx = self._fusion_bwd(sv, dfused, need, grads)
         enc_need = any(need.get(n, False) for n in self._names["full"] if n.startswith(("phasegram_encoder.", "stft_encoder.")))
         if not enc_need:
             return grads
-        dseq = ops.gemm(dgx[:, :1024], self.lstm.weight_ih_l0.detach(), trans_b=True, precise=pr)
-        ops.gemm(dgx[:, 1024:], self.lstm.weight_ih_l0_reverse.detach(), trans_b=True, out=dseq, beta=1, precise=pr)
+        dseq = self._fusion_dseq(dgx)
         flat_d, flat_o = dseq.view(-1), sv["seq"].view(-1)
         self._stack_backward("pgram_enc", sv["s_v"], None, need, grads, dcur_strided=(flat_d, flat_o))
         off = self.c_v * w

@@ -80,6 +80,15 @@ def stft_decoder_plan(t_a, n_bins, t_v, s_v, latent, c_stft):
     return plan
 
 
+def _bn_eval_reduce(sums):
+    """BatchNorm backward for a forward that used RUNNING statistics: mean and variance do not depend on the batch, so
+    dy = gamma * invstd * g without the batch-mean terms.  The split backward (ops.bn_pool_act_bwd with `reduce_fn`) takes the
+    dx coefficients from this [2C + 1] vector (sum g, sum g * xhat, count) and dgamma / dbeta from the untouched local copy:
+    zeroing the two sums is the eval-mode formula."""
+    sums[:-1].zero_()
+    return sums
+
+
 def _mark_touched(model, grads):
     """tell a FusedAdam built on this model which parameters just received a gradient (torch.optim.Adam skips the rest)"""
     flat = getattr(model, "_maavss_flat", None)
@@ -99,12 +108,11 @@ class _AVSEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_a, d_v, d_fused):
         model = ctx.model
-        if not ctx.was_training:
-            raise _lib.MaavssError("backward through an eval-mode forward (running-statistics BatchNorm) is not built; "
-                                   "call model.train() for training steps")
         names = model._param_names
         need = {n: ctx.needs_input_grad[3 + i] for i, n in enumerate(names)}
-        grads = model._engine_backward(ctx.saved, d_a, d_v, d_fused, need)
+        # eval-mode forward: BatchNorm normalised with its running statistics, which do not depend on the batch -- its
+        # backward has no batch-mean terms (torch autograd allows this; fine-tuning with frozen statistics)
+        grads = model._engine_backward(ctx.saved, d_a, d_v, d_fused, need, bn_eval=not ctx.was_training)
         ctx.saved = None
         _mark_touched(model, grads)
         return (None, None, None) + tuple(grads.get(n) for n in names)
@@ -162,10 +170,7 @@ class _AEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         model = ctx.model
-        if not ctx.was_training:
-            raise _lib.MaavssError("backward through an eval-mode forward (running-statistics BatchNorm) is not built; "
-                                   "call model.train() for training steps")
-        grads = model._ae_backward(ctx.saved, d_out.contiguous().float())
+        grads = model._ae_backward(ctx.saved, d_out.contiguous().float(), bn_eval=not ctx.was_training)
         ctx.saved = None
         _mark_touched(model, {n: g for i, (n, g) in enumerate((n, grads.get(n)) for n in model._ae_param_names)
                               if ctx.needs_input_grad[2 + i]})
@@ -364,8 +369,9 @@ class AV_Fusion_Model_Frames(nn.Module):
             sv["dec"].append(rec)
         return cur, sv
 
-    def _ae_backward(self, sv, d_out):
+    def _ae_backward(self, sv, d_out, bn_eval=False):
         grads = {}
+        bn_reduce = _bn_eval_reduce if bn_eval else None
         b = d_out.shape[0]
         dcur = d_out                                    # NCHW gradient of the last (BN-less) layer's output
         for j in reversed(range(len(self._dec_plan))):
@@ -378,7 +384,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 gw = torch.empty(co_p, device=d_out.device, dtype=torch.float32)
                 gb = torch.empty(co_p, device=d_out.device, dtype=torch.float32)
                 dy = ops.bn_pool_act_bwd(dcur.view(b, 1, ho, wo, co_p), s["out"], None, s["y"], s["mean"], s["invstd"], s["gamma"], 1,
-                                         ops.BN_TANH, dgamma=gw, dbeta=gb).view(b, ho, wo, co_p)
+                                         ops.BN_TANH, dgamma=gw, dbeta=gb, reduce_fn=bn_reduce).view(b, ho, wo, co_p)
                 grads[f"stft_decoder.{idx + 1}.weight"] = gw[:co].clone()
                 grads[f"stft_decoder.{idx + 1}.bias"] = gb[:co].clone()
             else:
@@ -395,7 +401,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             gw = torch.empty(co, device=d_out.device, dtype=torch.float32)
             gb = torch.empty(co, device=d_out.device, dtype=torch.float32)
             dy = ops.bn_pool_act_bwd(dcur.view(b, 1, ho, wo, co), s["out"], None, s["y"], s["mean"], s["invstd"], bn.weight.detach(), 1,
-                                     ops.BN_TANH, dgamma=gw, dbeta=gb).view(b, ho, wo, co)
+                                     ops.BN_TANH, dgamma=gw, dbeta=gb, reduce_fn=bn_reduce).view(b, ho, wo, co)
             grads[f"stft_encoder.{3 * i + 1}.weight"], grads[f"stft_encoder.{3 * i + 1}.bias"] = gw, gb
             grads[f"stft_encoder.{3 * i}.weight"] = ops.conv2d_wgrad(s["x"], dy, conv.weight.shape, st, pw, s["nchw"])
             if i > 0:
@@ -543,7 +549,8 @@ class AV_Fusion_Model_Frames(nn.Module):
         v_out = v.view(b, self.frame_channels, w, w)
         return (a_out, v_out, fused), sv
 
-    def _engine_backward(self, sv, d_a, d_v, d_fused, need, grads=None, accumulate=False, on_fusion_done=None, on_grad=None):
+    def _engine_backward(self, sv, d_a, d_v, d_fused, need, grads=None, accumulate=False, on_fusion_done=None, on_grad=None,
+                         bn_eval=False):
         """Hand-written backward.  `need[name]` says which parameter gradients are wanted; results go into
         `grads[name]` (pre-allocated when `grads` is given -- e.g. views of a flat gradient buffer --,
         `accumulate` then adds instead of overwriting).  `on_fusion_done` is called once the gradients of the
@@ -552,6 +559,7 @@ class AV_Fusion_Model_Frames(nn.Module):
         all-reduce starts while fc2 / fc1 / the LSTM are still in their backward pass)."""
         # conv backward operands: bf16 (gradients need the exponent range), or exact f32; Linear layers always f32
         pr_conv, pr = (ops.MODE_F32 if self.precise else ops.MODE_BF16), ops.MODE_F32
+        bn_reduce = _bn_eval_reduce if bn_eval else self._bn_sync       # `bn_eval`: the forward used running statistics
         out_grads = {}
         pd = dict(self.named_parameters())
 
@@ -630,7 +638,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 dout, out, strides = dcur.view(b, 1, ho, wo, co), s["out"], None
             gw, gb, acc = bn_grads("stft_encoder", 3 * i + 1)
             dy = ops.bn_pool_act_bwd(dout, out, None, s["y"], s["mean"], s["invstd"], bn.weight.detach(), 1, ops.BN_TANH,
-                                     strides=strides, dgamma=gw, dbeta=gb, accumulate=acc, reduce_fn=self._bn_sync).view(b, ho, wo, co)
+                                     strides=strides, dgamma=gw, dbeta=gb, accumulate=acc, reduce_fn=bn_reduce).view(b, ho, wo, co)
             wname = f"stft_encoder.{3 * i}.weight"
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
@@ -656,7 +664,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 # forms it in its loader from the pooled gradient (no 1.6 GB dy tensor, no dx pass)
                 coef = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
                                            ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(), coef_only=True,
-                                           reduce_fn=self._bn_sync)
+                                           reduce_fn=bn_reduce)
                 if need.get(wname, False):
                     buf, beta = gbuf(wname)
                     ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
@@ -666,7 +674,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             # 16-bit path: dy is written as bf16 -- what both of its consumers (weight gradient, input gradient) round it to
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
                                      ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(),
-                                     reduce_fn=self._bn_sync, dy_bf16=not self.precise)
+                                     reduce_fn=bn_reduce, dy_bf16=not self.precise)
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:
