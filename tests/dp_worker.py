@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--sync-bn", type=int, default=0)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--adam", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--freeze-enc-after", type=int, default=-1, help="toggle_enc_grads(False) before this step index")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -39,12 +41,18 @@ def main():
     step = maavss_amd.TrainStep(model, lr=1e-3, loss_coeff=0.001, num_seq=1, sync_bn=bool(args.sync_bn))
     x_a, x_v, y_a, y_v = orc.synthetic_batch(args.batch, t, w, t_a, n_bins, hpf, 32)
     lo, hi = maavss_amd.shard_batch(args.batch, rank, world)
-    losses = step(x_a[lo:hi].cuda(), x_v[lo:hi].cuda(), y_a[lo:hi].cuda(), y_v[lo:hi].cuda(), optimizer_step=bool(args.adam))
+    logs = []
+    for i in range(args.steps):
+        if i == args.freeze_enc_after:
+            model.toggle_enc_grads(False)      # the encoders' last gradients stay in the flat buffer: they must not be re-reduced
+        losses = step(x_a[lo:hi].cuda(), x_v[lo:hi].cuda(), y_a[lo:hi].cuda(), y_v[lo:hi].cuda(), optimizer_step=bool(args.adam))
+        logs.append(list(step.sync.launch_log))
     torch.cuda.synchronize()
     grads = {n: (g / world).cpu() for n, g in step.flat.grad_views.items()}
     out = {"grads": grads, "losses": losses.cpu(), "a_out": step.outputs[0].cpu(),
            "bn": {k: v.cpu() for k, v in model.named_buffers() if not k.startswith("stft_")},
-           "params_sum": float(step.flat.params.double().sum().item())}
+           "params_sum": float(step.flat.params.double().sum().item()), "params": step.flat.params.cpu(), "launch_logs": logs,
+           "enc_grad_absmax": float(step.flat.grads[step.flat.fusion_end:].abs().max().item())}
     torch.save(out, os.path.join(args.out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

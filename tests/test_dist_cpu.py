@@ -50,6 +50,64 @@ def test_gradsync_and_sharding_world2(tmp_path):
     assert max(sizes) - min(sizes) <= 1
 
 
+class _FakeFlat:
+    """the part of trainer.FlatParams GradSync reads: names in buffer order, offsets, shapes"""
+    def __init__(self):
+        self.names = ["lstm.w_ih", "lstm.w_hh", "fc1.weight", "fc2.weight", "a_fc1.0.weight", "v_fc1.0.weight", "enc.0.weight", "enc.1.bias"]
+        sizes = [64, 64, 256, 128, 64, 192, 100, 28]
+        self.offsets, self.shapes, off = {}, {}, 0
+        for n, k in zip(self.names, sizes):
+            self.offsets[n], self.shapes[n] = off, (k,)
+            off = (off + k + 63) // 64 * 64
+        self.total, self.fusion_end = off, self.offsets["enc.0.weight"]
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maavss_amd.trainer import GradSync
+    flat = _FakeFlat()
+    g = torch.zeros(flat.total)
+    sync = GradSync(g, flat.fusion_end, flat=flat)
+    assert [b["key"] for b in sync.buckets] == ["lstm", "fc1", "fc2", "a_fc1", "v_fc1", "encoders"]
+    tot = float(sum(r + 1 for r in range(world)))
+    # step 1: everything receives a gradient, in backward order; each bucket goes out the moment it is complete
+    g.fill_(rank + 1.0)
+    sync.begin(flat.names)
+    for n in ("a_fc1.0.weight", "v_fc1.0.weight", "fc2.weight", "fc1.weight", "lstm.w_ih"):
+        sync.grad_ready(n)
+    assert sync.launch_log == ["a_fc1", "v_fc1", "fc2", "fc1"]          # lstm waits for its second weight
+    sync.grad_ready("lstm.w_hh")
+    assert sync.launch_log[-1] == "lstm"
+    sync.finish()
+    assert sync.launch_log[-1] == "encoders" and torch.equal(g, torch.full_like(g, tot))
+    # step 2: the encoders and fc1 are frozen.  Their stale gradients (here: 7) must neither be summed nor be touched where the
+    # whole bucket is skipped; a frozen parameter INSIDE a reduced bucket (lstm.w_hh) is zeroed before the reduction
+    g.fill_(rank + 1.0)
+    lo, hi = flat.offsets["enc.0.weight"], flat.total
+    g[lo:hi] = 7.0
+    g[flat.offsets["fc1.weight"]:flat.offsets["fc2.weight"]] = 7.0
+    g[flat.offsets["lstm.w_hh"]:flat.offsets["fc1.weight"]] = 7.0
+    expected = ["lstm.w_ih", "fc2.weight", "a_fc1.0.weight", "v_fc1.0.weight"]
+    sync.begin(expected)
+    for n in ("a_fc1.0.weight", "v_fc1.0.weight", "fc2.weight", "lstm.w_ih"):
+        sync.grad_ready(n)
+    sync.finish()
+    assert torch.equal(g[lo:hi], torch.full((hi - lo,), 7.0))                                  # skipped bucket: untouched
+    assert torch.equal(g[flat.offsets["fc1.weight"]:flat.offsets["fc2.weight"]], torch.full((256,), 7.0))
+    assert torch.equal(g[flat.offsets["lstm.w_hh"]:flat.offsets["fc1.weight"]], torch.zeros(64))   # zeroed, then summed: 0
+    for n in expected:
+        o = flat.offsets[n]
+        assert torch.equal(g[o:o + flat.shapes[n][0]], torch.full((flat.shapes[n][0],), tot)), n
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_buckets_follow_the_backward_order_and_skip_frozen_parameters_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+
 def test_shard_batch_covers_everything():
     from maavss_amd.trainer import shard_batch
     for world in (1, 2, 4, 8):

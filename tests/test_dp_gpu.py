@@ -46,13 +46,13 @@ def _single_process(lo, hi):
             {k: v.cpu().clone() for k, v in model.named_buffers() if not k.startswith("stft_")})
 
 
-def _run_ranks(tmp_path, sync_bn):
-    out = tmp_path / f"dp_sync{int(sync_bn)}"
+def _run_ranks(tmp_path, sync_bn, extra=()):
+    out = tmp_path / f"dp_sync{int(sync_bn)}{len(extra)}"
     out.mkdir()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), "--out", str(out),
-           "--sync-bn", str(int(sync_bn)), "--batch", str(B)]
+           "--sync-bn", str(int(sync_bn)), "--batch", str(B), *extra]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load(out / f"rank{k}.pt", weights_only=True) for k in range(2)]
@@ -99,3 +99,18 @@ def test_two_ranks_without_sync_bn_equal_the_mean_of_the_shard_gradients(tmp_pat
     rel = (ranks[0]["grads"]["fc1.weight"] - g_full["fc1.weight"]).norm() / g_full["fc1.weight"].norm()
     print(f"[dp] per-rank BatchNorm vs global-batch BatchNorm: fc1.weight gradient differs by {rel.item():.3e} (relative L2)")
     assert rel.item() > 1e-4
+
+
+def test_three_adam_steps_leave_the_replicas_bit_identical_and_buckets_launch_in_backward_order(tmp_path):
+    """the round-2 tests stopped before opt.step().  Three TrainSteps WITH Adam on two ranks (different
+    shards, rank 1 starting from other weights): the flat parameter buffers must be bit-identical afterwards (same reduced
+    gradients -> same update).  The gradient buckets are launched in the order the backward pass completes them (heads, fc2,
+    fc1, lstm, then the encoders).  Before the third step the encoders are frozen: their bucket is no longer reduced, so the
+    stale gradients in the flat buffer are not multiplied by the world size step after step."""
+    ranks = _run_ranks(tmp_path, sync_bn=True, extra=("--adam", "1", "--steps", "3", "--freeze-enc-after", "2"))
+    assert torch.equal(ranks[0]["params"], ranks[1]["params"])
+    assert ranks[0]["params"].abs().sum().item() > 0
+    for r in ranks:
+        assert r["launch_logs"][0] == ["a_fc1", "v_fc1", "fc2", "fc1", "lstm", "encoders"], r["launch_logs"][0]
+        assert r["launch_logs"][2] == ["a_fc1", "v_fc1", "fc2", "fc1", "lstm"], r["launch_logs"][2]
+    assert ranks[0]["enc_grad_absmax"] == ranks[1]["enc_grad_absmax"] and ranks[0]["enc_grad_absmax"] < 1e6

@@ -20,9 +20,15 @@ WAIT = """\t;;#ASMSTART
 """
 
 
-def kernel(between_loop_fetch_and_wait="\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n", extra=""):
-    return ("_Z18vit_ws_gemm_kernelILi0ELi0ELi2EEv6WsArgs: ; @kernel\n" + FETCH + "\tv_add_u32_e32 v1, v2, v3\n" + WAIT +
-            "\tds_write_b128 v5, v[112:115]\n.LBB0_1:\n\ts_barrier\n" + FETCH + between_loop_fetch_and_wait + WAIT +
+WAIT0 = WAIT.replace("vmcnt(4)", "vmcnt(0)")
+# one half-panel step: MFMA + two output stores, executed twice (inner loop) between the fetch and its vmcnt(4) wait
+HALF_STEPS = (".LBB0_2:\n\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n\tglobal_store_dwordx4 v[30:31], v[40:43], off\n"
+              "\tglobal_store_dwordx4 v[30:31], v[44:47], off offset:32\n\ts_cbranch_scc0 .LBB0_2\n")
+
+
+def kernel(between_loop_fetch_and_wait="", extra="", steps=HALF_STEPS):
+    return ("_Z18vit_ws_gemm_kernelILi0ELi0ELi2EEv6WsArgs: ; @kernel\n" + FETCH + "\tv_add_u32_e32 v1, v2, v3\n" + WAIT0 +
+            "\tds_write_b128 v5, v[112:115]\n.LBB0_1:\n\ts_barrier\n" + FETCH + steps + between_loop_fetch_and_wait + WAIT +
             "\tds_write_b128 v5, v[112:115]\n" + extra + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
 
 
@@ -48,3 +54,12 @@ def test_spill_is_rejected(tmp_path):
 def test_fetch_without_wait_is_rejected(tmp_path):
     text = kernel().replace(WAIT + "\tds_write_b128 v5, v[112:115]\n\ts_cbranch", "\ts_cbranch")
     assert run(tmp_path, text) == 1
+
+
+def test_wait_that_counts_more_memory_operations_than_were_issued_is_rejected(tmp_path):
+    """vmcnt(4) after a fetch is only a wait FOR the fetch if four younger vector-memory operations exist"""
+    one_store = HALF_STEPS.replace("\tglobal_store_dwordx4 v[30:31], v[44:47], off offset:32\n", "")
+    assert run(tmp_path, kernel(steps=one_store)) == 1                    # 2 x 1 store < 4
+    straight = HALF_STEPS.replace(".LBB0_2:\n", "").replace("\ts_cbranch_scc0 .LBB0_2\n", "")
+    assert run(tmp_path, kernel(steps=straight)) == 1                     # the same two stores, not in a loop: 2 < 4
+    assert run(tmp_path, kernel(steps=straight + straight)) == 0          # unrolled: 4
