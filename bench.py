@@ -216,7 +216,7 @@ def main():
     sync_all()
     # HIP events around the entry points the roofline / stage rows are made of (the ViT GEMMs and attention, STFT, Adam); with
     # --verbose around every entry point (155 launches per step: the event pairs then cost ~0.9 ms of the step)
-    staged = ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
+    staged = ("maavss_vit_attn", "maavss_vit_attn_mx", "maavss_vit_ws_gemm_ln_mx", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
               "maavss_vit_gemm", "maavss_vit_gemm_stats", "maavss_stft_fwd", "maavss_adam_step")
     timer = _lib.KernelTimer(only=None if args.verbose else staged)
     _lib.set_timer(timer)
@@ -265,8 +265,10 @@ def main():
                 return 2.0 * a[11] * a[12] * 384                  # M, N, K = 384 (LayerNorm flops not counted)
             if name == "maavss_vit_attn":
                 return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # frames * heads * ntok^2 * 64 * (QK^T + PV)
-            if name == "maavss_vit_attn_fp8":
-                return 4.0 * a[3] * a[5] * a[4] * a[4] * 64
+            if name == "maavss_vit_attn_mx":
+                return 4.0 * a[2] * a[4] * a[3] * a[3] * 64       # (ws, out, frames, ntok, heads, ...)
+            if name == "maavss_vit_ws_gemm_ln_mx":
+                return 2.0 * a[9] * 1152 * 384                    # M, N = 1152, K = 384
             return 0.0
         def bytes_of(name, a):
             """Algorithmic HBM bytes of one launch: every operand read once, every result written once."""
@@ -286,8 +288,10 @@ def main():
                 return (4.0 * 384 + 24.0) * m + 2.0 * n * 384 + 2.0 * m * n
             if name == "maavss_vit_attn":
                 return a[2] * a[3] * (1152 + 384) * 2.0             # qkv in, attention output out, bf16
-            if name == "maavss_vit_attn_fp8":
-                return a[3] * a[4] * (1152 + 384) * 2.0
+            if name == "maavss_vit_attn_mx":
+                return a[2] * a[3] * (1152 * 1.0 + 1152 / 32.0 + 384 * 2.0)      # fp8 images + scale bytes in, 16-bit out
+            if name == "maavss_vit_ws_gemm_ln_mx":
+                return (4.0 * 384 + 24.0) * a[9] + 2.0 * 1152 * 384 + a[9] * (1152 * 1.0 + 1152 / 32.0)
             return 0.0
         by_time = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
         dom_name, dom = by_time[0]
@@ -338,7 +342,7 @@ def main():
             if bytes_:
                 row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
             stages[name.replace("maavss_", "")] = row
-        for nm in ("maavss_vit_attn", "maavss_vit_attn_fp8", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
+        for nm in ("maavss_vit_attn", "maavss_vit_attn_mx", "maavss_vit_ws_gemm_ln_mx", "maavss_vit_panel_gemm", "maavss_vit_ws_gemm", "maavss_vit_ws_gemm_ln",
                    "maavss_vit_gemm", "maavss_vit_gemm_stats"):
             if nm in summ:
                 stage_row(nm, sum(flops_of(nm, a) for a in summ[nm]["args"]), sum(bytes_of(nm, a) for a in summ[nm]["args"]))
@@ -405,7 +409,7 @@ def main():
                                    f"({args.vit_dtype} MFMA operands, f32 accumulate) + STFT + AV_Fusion_Model_Frames fwd+bwd (16-bit MFMA conv, f32 accumulate) + Adam",
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
                        "parallelism": f"dp{world}", "streams": "2 (extraction of batch i+1 under the training step of batch i)" if pipe is not None else "1", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
-                       "vit": args.vit_dtype, "vit_attention": "fp8 e4m3" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
+                       "vit": args.vit_dtype, "vit_attention": "block-scaled fp8 (MX e4m3, e8m0 scale per 32; f32 accumulate -- wider than the config's bf16)" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
                        "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank",
                        "loss": loss_val},
             "roofline": roofline,

@@ -283,13 +283,22 @@ int maavss_vit_gemm_stats(const void* A, int lda, const void* W, const float* bi
 int maavss_vit_attn(const void* qkv, void* out, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
                     void* stream);
 int maavss_vit_cls_attn(const void* qkv, float* att, int frames, int ntok, int heads, int ld_qkv, int dtype, void* stream);
-/* fp8 (OCP e4m3) attention, BASELINE config "fp8 MFMA attention QK^T / AV" -- same call site (video_attention.py:52), same
- * qkv / out tensors and layouts as maavss_vit_attn (`dtype` = their 16-bit format).  Per (frame, head) q, k and v are scaled
- * by absmax / 448 and stored as e4m3 in `ws` (maavss_vit_attn_fp8_ws_bytes bytes, 16-byte aligned); Q K^T and P V run on
- * v_mfma_f32_32x32x16_fp8_fp8 with f32 accumulation, the softmax in f32. */
-int64_t maavss_vit_attn_fp8_ws_bytes(int frames, int ntok, int heads);
-int maavss_vit_attn_fp8(const void* qkv, void* out, void* ws, int frames, int ntok, int heads, int ld_qkv, int ld_out, int dtype,
-                        void* stream);
+/* Block-scaled fp8 attention, BASELINE config "fp8 MFMA attention QK^T / AV" (round 3; replaces round 2's non-scaled fp8 kernel) --
+ * same call site (video_attention.py:52) and the out tensor / layout of maavss_vit_attn: Q K^T and P V on v_mfma_scale_f32_32x32x64_f8f6f4 (OCP MX:
+ * e4m3 elements, one e8m0 scale per 32-element K block; f32 accumulation -- the config's "bf16 accumulate" is f32 here, wider).
+ * `ws` (maavss_vit_attn_mx_ws_bytes(rows) bytes, 256-byte aligned, rows = frames * ntok) holds the operand images laid out in
+ * csrc/vit_mx.h: q8 / k8 [rows_alloc][384] with per-(token, head, 32 d) scales, V transposed [384][rows_alloc] with per-(d row,
+ * 32-token block) scales.  They are written either by maavss_vit_qkv_mx from a 16-bit qkv tensor, or directly by the attn.qkv
+ * GEMM (maavss_vit_ws_gemm_ln_mx: no 16-bit qkv, no quantisation pass).  `dtype` = the 16-bit format of out (and of qkv). */
+int64_t maavss_vit_attn_mx_ws_bytes(int64_t rows);
+int maavss_vit_qkv_mx(const void* qkv, void* ws, int64_t rows, int ld_qkv, int dtype, void* stream);
+int maavss_vit_attn_mx(const void* ws, void* out, int frames, int ntok, int heads, int ld_out, int dtype, void* stream);
+/* attn.qkv (N = 1152) with norm1 applied on the way in, exactly as maavss_vit_ws_gemm_ln, but the epilogue writes the images above
+ * into `mx_ws` (maavss_vit_attn_mx_ws_bytes(M) bytes; bytes past the stored panels must be zero -- allocate zeroed once) instead
+ * of a 16-bit qkv tensor: no quantisation pass, half the output bytes.  `dtype` = the 16-bit format of W. */
+int maavss_vit_ws_gemm_ln_mx(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
+                             float ln_eps, const void* W, const float* bias, void* mx_ws, int64_t M, int qscale_cols, float qscale,
+                             int dtype, void* stream);
 int maavss_vit_attn_maps(const float* att, float* out, float* ws, int64_t n_frames, int heads, int H, int W,
                          int clip_frames, int attn_diff /* av_dataset.py:323-326, needs clip_frames > 0 */, void* stream);
 /* Same, and sets *nonfinite_flag (device int32, sticky, never cleared here; null = no check) to 1 when any CLS-attention value

@@ -20,9 +20,15 @@
 //   * one workgroup barrier per panel.
 // Epilogues: 0 +bias, q-scale -> 16-bit | 1 +bias, GELU -> 16-bit | 2 +bias +residual -> f32 in place, and optionally the
 // NEXT LayerNorm of the updated rows -> 16-bit (ns = 1: the workgroup holds whole rows), so that the consumer GEMM needs no
-// LayerNorm pass.
+// LayerNorm pass | 3 (round 3, attn.qkv only, N = 1152): +bias, q-scale -> the BLOCK-SCALED fp8 operand images of the attention
+// kernel (vit_mx.h) instead of a 16-bit qkv tensor: the q and k slices per (token, 32 columns) -- a wave's 32 output columns are
+// one scale block, absmax over a lane's 16 values + one lane swap --, the v slice TRANSPOSED: its workgroups issue the MFMA with
+// the operands exchanged (weights as B), so a lane holds one d column and 16 tokens of a 32-token block, quantises per (d, block)
+// and stores 16 consecutive token bytes of a V^T row.  No quantisation pass, 1 byte per element written instead of 2.
+#include <type_traits>
 #include "mma.h"
 #include "vit_epilogue.h"
+#include "vit_mx.h"
 
 #define WS_K 384
 #define WS_BM 64
@@ -49,13 +55,15 @@ struct WsArgs {
   int ns;                // column slices of 384
   int groups_per_xcd;    // (CUs per XCD) / ns
   int panels;            // ceil(M / 64)
+  MxImages mx;           // epi 3
 };
 
 template <int EPI, int LN, int MODE>
 __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   constexpr bool LN_OUT = LN == 1, LN_IN = LN == 2;
   static_assert(!LN_OUT || EPI == 2, "LayerNorm of the output rows comes with the residual epilogue");
-  static_assert(!LN_IN || EPI == 0, "LayerNorm on the way in is wired for the 16-bit bias epilogue (attn.qkv)");
+  static_assert(!LN_IN || EPI == 0 || EPI == 3, "LayerNorm on the way in is wired for the attn.qkv epilogues");
+  static_assert(EPI != 3 || LN_IN, "the MX epilogue is wired for attn.qkv (LayerNorm on the way in)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* panels_lds = smem;                                                       // 2 x 48 KiB
   float* bias_lds = reinterpret_cast<float*>(smem + WS_BUFS * WS_PANEL_BYTES);   // [384] (+ [384] gamma, [384] beta, stats)
@@ -215,9 +223,12 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // fragment read address: activation row r32 (+ 32 h2), chunk 2 kb + half, kb = 8 a + b:
   //   ((2 b + half) ^ (r32 & 15)) << 4  =  (((b << 5) ^ ((r32 & 14) << 4))) + ((half ^ (r32 & 1)) << 4)
   const int frag_r = r32 * (WS_K * 2) + ((half ^ (r32 & 1)) << 4), frag_x = (r32 & 14) << 4;
-  const float scale = (EPI == 0 && slice * WS_SLICE < g.qscale_cols) ? g.qscale : 1.f;   // qscale_cols is a multiple of 384
+  const float scale = ((EPI == 0 || EPI == 3) && slice * WS_SLICE < g.qscale_cols) ? g.qscale : 1.f;   // qscale_cols is a multiple of 384
+  const bool vslice = EPI == 3 && slice == 2;          // attn.qkv -> MX images: the v slice runs with the MFMA operands exchanged
 
-  constexpr int S = EPI == 2 ? (LN_OUT ? 20 : 16) : 4;   // vector-memory operations of one panel epilogue (loads + stores)
+  // vector-memory operations of one panel epilogue (loads + stores) that the hand-counted wait may leave in flight.  EPI 3: a
+  // half-panel issues 3 (q, k slices: two 8-byte stores + the scale byte) or 2 (v slice: one 16-byte store + the scale byte)
+  constexpr int S = EPI == 2 ? (LN_OUT ? 20 : 16) : 4;
   int it = 0;
   for (int p = p0; p < p1; ++p, ++it) {
     const int buf = it & 1;
@@ -245,6 +256,14 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
         const float4 bq = *reinterpret_cast<const float4*>(bias_lds + wv * 32 + 16 * (q >> 1) + 8 * half + 4 * (q & 1));
         acc[4 * q + 0] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
       }
+      if (EPI == 3 && vslice) {   // exchanged operands: this lane's output column is weight row n0 + pi(r32), all 16 registers
+        int to = tid;
+        asm volatile("" : "+v"(to));
+        const int r32o = to & 31;
+        const float bl = bias_lds[(to >> 6) * 32 + 16 * (r32o >> 4) + 8 * ((r32o >> 2) & 1) + 4 * ((r32o >> 3) & 1) + (r32o & 3)];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = bl;
+      }
       auto rd = [&](int kb) __attribute__((always_inline)) {
         // The GELU epilogue makes fc1 vector-ISSUE bound (PMC: 8.5 VALU instructions per MFMA; a 32x32x16 MFMA leaves room for
         // six): there the eight fragment addresses are precomputed (registers paid for with one step less of read-ahead).  The
@@ -255,17 +274,28 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
       };
       // fragment reads kept in flight ahead of the MFMA that consumes them (the residual epilogues are HBM-bound and short of
       // registers: one)
-      constexpr int WS_DEPTH = EPI == 2 ? 1 : (LN_IN || EPI == 1) ? 2 : 3;
-      bf16x8 f[WS_DEPTH + 1];
+      constexpr int WS_DEPTH = (EPI == 2 || EPI == 3) ? 1 : (LN_IN || EPI == 1) ? 2 : 3;
+      auto mfma_loop = [&](auto swapped_c) __attribute__((always_inline)) {
+        constexpr bool SWAPPED = decltype(swapped_c)::value;   // C^T = X W^T: lane = output column, registers = rows (EPI 3, v slice)
+        bf16x8 f[WS_DEPTH + 1];
 #pragma unroll
-      for (int kb = 0; kb < WS_DEPTH; ++kb) f[kb] = rd(kb);
+        for (int kb = 0; kb < WS_DEPTH; ++kb) f[kb] = rd(kb);
 #pragma unroll
-      for (int kb = 0; kb < 24; ++kb) {
-        if (kb + WS_DEPTH < 24 && !(abl & 8)) f[(kb + WS_DEPTH) % (WS_DEPTH + 1)] = rd(kb + WS_DEPTH);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(abl & 4)) Mma32<MODE>::mma(acc, w[kb], f[kb % (WS_DEPTH + 1)]);
-        else if (kb == 23) acc[0] += (float)(f[0][0] + f[1][1] + f[2][2] + f[3][3]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int kb = 0; kb < 24; ++kb) {
+          if (kb + WS_DEPTH < 24 && !(abl & 8)) f[(kb + WS_DEPTH) % (WS_DEPTH + 1)] = rd(kb + WS_DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(abl & 4)) {
+            if constexpr (SWAPPED) Mma32<MODE>::mma(acc, f[kb % (WS_DEPTH + 1)], w[kb]);
+            else Mma32<MODE>::mma(acc, w[kb], f[kb % (WS_DEPTH + 1)]);
+          } else if (kb == 23) acc[0] += (float)(f[0][0] + f[1][1] + f[2][2] + f[3][3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if constexpr (EPI == 3) {
+        if (vslice) mfma_loop(std::true_type{});
+        else mfma_loop(std::false_type{});
+      } else {
+        mfma_loop(std::false_type{});
       }
 
       // ---- epilogue: lane (r32, half) holds, of row m0 + 32 h2 + r32, the columns n0 + 16 qp + 8 half + (0..7), qp = 0, 1
@@ -273,7 +303,40 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
       bool skip_epi = false;
       if constexpr ((abl & 1) != 0) skip_epi = acc[3] != 1234.5f;
       if (!skip_epi) {
-      if constexpr (EPI != 2) {
+      if constexpr (EPI == 3) {
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] *= scale; amax = fmaxf(amax, fabsf(acc[e])); }
+        float ma, mb;
+        lane_swap32(amax, ma, mb);
+        float inv;
+        const unsigned eb = mx_scale_byte(fmaxf(ma, mb), inv);
+        unsigned qd[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) qd[q4] = mx_cvt4(acc[4 * q4] * inv, acc[4 * q4 + 1] * inv, acc[4 * q4 + 2] * inv, acc[4 * q4 + 3] * inv);
+        // every per-lane address below is derived from an opaque copy of the thread index: the compiler then cannot hoist them
+        // out of the panel loop into permanently live registers (this kernel has none to spare)
+        int to = tid;
+        asm volatile("" : "+v"(to));
+        const int r32o = to & 31, halfo = (to >> 5) & 1, wvo = to >> 6;
+        if (!vslice) {
+          // lane (row r32, half): columns 16 qp + 8 half + (0..7) of the wave's 32 = dwords (2 qp, 2 qp + 1); scale plane = wv
+          const int64_t rowo = m0 + 32 * h2 + r32o;
+          unsigned char* dst = (slice == 0 ? g.mx.q8 : g.mx.k8) + rowo * MX_DIM + wvo * 32 + 8 * halfo;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(qd[0], qd[1]);
+          *reinterpret_cast<uint2*>(dst + 16) = make_uint2(qd[2], qd[3]);
+          if (halfo == 0) (slice == 0 ? g.mx.sq : g.mx.sk)[(int64_t)wvo * g.mx.rows_alloc + rowo] = (unsigned char)eb;
+        } else {
+          // lane (d column, half): registers (g, i) = token 8 g + 4 half + i of the half panel.  Two lane swaps hand each half 16
+          // CONSECUTIVE tokens: half 0 -> (own q0, other q0, own q1, other q1) = tokens 0..15, half 1 -> tokens 16..31
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(qd[0]), "+v"(qd[2]));
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(qd[1]), "+v"(qd[3]));
+          const int dcol = wvo * 32 + 16 * (r32o >> 4) + 8 * ((r32o >> 2) & 1) + 4 * ((r32o >> 3) & 1) + (r32o & 3);
+          const int64_t tok0 = m0 + 32 * h2;
+          *reinterpret_cast<uint4*>(g.mx.v8t + (int64_t)dcol * g.mx.rows_alloc + tok0 + 16 * halfo) = make_uint4(qd[0], qd[2], qd[1], qd[3]);
+          if (halfo == 0) g.mx.sv[(tok0 >> 5) * MX_DIM + dcol] = (unsigned char)eb;
+        }
+      } else if constexpr (EPI != 2) {
         bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + row * g.ldc + n0 + 8 * half;
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
@@ -366,7 +429,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
 
 static int ws_gemm_launch(const char* who, const void* A, const float* X, const float* row_stats, const void* W, const float* bias,
                           void* C, int ldc, int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
-                          const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream) {
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream, void* mx_ws = nullptr) {
   static int n_cu_dev[64] = {0};
   int dev = 0;
   MAAVSS_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "%s: cannot query the device", who);
@@ -380,6 +443,7 @@ static int ws_gemm_launch(const char* who, const void* A, const float* X, const 
   g.A = (const bf16_t*)A; g.X = X; g.row_stats = row_stats; g.W = (const bf16_t*)W; g.bias = bias; g.C = C; g.XN = (bf16_t*)xn_out;
   g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps;
   g.M = (int)M; g.N = N; g.ldc = ldc; g.qscale_cols = qscale_cols; g.qscale = qscale;
+  if (mx_ws) g.mx = mx_images(mx_ws, M);
   g.ns = N / WS_SLICE;
   MAAVSS_CHECK_ARG(g.ns <= cu_per_xcd, "%s: N too large for one XCD's CUs", who);
   g.groups_per_xcd = cu_per_xcd / g.ns;
@@ -393,7 +457,7 @@ static int ws_gemm_launch(const char* who, const void* A, const float* X, const 
     hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                      \
   }
 #define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
-  if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
+  if (X && epilogue == 3) WS_LAUNCH(3, 2) else if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
 #undef WS_LAUNCH3
 #undef WS_LAUNCH
   MAAVSS_LAUNCH_CHECK("vit_ws_gemm_kernel");
@@ -431,4 +495,18 @@ extern "C" int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm_ln: ldc must be a multiple of 8, qscale_cols a multiple of 384");
   return ws_gemm_launch("vit_ws_gemm_ln", nullptr, X, row_stats, W, bias, C, ldc, M, N, 0, qscale_cols, qscale, nullptr, ln_gamma, ln_beta, ln_eps,
                         dtype, stream);
+}
+
+// attn.qkv with LayerNorm on the way in (as maavss_vit_ws_gemm_ln) writing the block-scaled fp8 operand images of
+// maavss_vit_attn_mx into `mx_ws` (maavss_vit_attn_mx_ws_bytes(M) bytes) instead of a 16-bit qkv tensor.  N = 1152.
+extern "C" int maavss_vit_ws_gemm_ln_mx(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
+                                        float ln_eps, const void* W, const float* bias, void* mx_ws, int64_t M, int qscale_cols, float qscale,
+                                        int dtype, void* stream) {
+  MAAVSS_CHECK_ARG(X && row_stats && ln_gamma && ln_beta && W && bias && mx_ws && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln_mx: bad arguments");
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm_ln_mx: dtype (of the weights) must be 0 (bf16) or 2 (f16)");
+  MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm_ln_mx: X needs ceil(M/64)*64 = %ld allocated rows (got %ld): whole panels are read",
+                   (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows);
+  MAAVSS_CHECK_ARG(qscale_cols % WS_SLICE == 0 && ((uintptr_t)mx_ws & 255) == 0, "vit_ws_gemm_ln_mx: qscale_cols must be a multiple of 384, mx_ws 256-byte aligned");
+  return ws_gemm_launch("vit_ws_gemm_ln_mx", nullptr, X, row_stats, W, bias, mx_ws, 3 * WS_SLICE, M, 3 * WS_SLICE, 3, qscale_cols, qscale, nullptr,
+                        ln_gamma, ln_beta, ln_eps, dtype, stream, mx_ws);
 }

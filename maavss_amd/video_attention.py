@@ -114,8 +114,9 @@ class VideoAttention:
             raise ValueError("act_dtype must be 'f16' or 'bf16'")
         self.act_dtype = act_dtype
         self.dt = DT_F16 if act_dtype == "f16" else DT_BF16
-        # attn_dtype="fp8": Q K^T and P V of the 11 full blocks on fp8 (e4m3) MFMA with per-(frame, head) scales
-        # (BASELINE config "fp8 MFMA attention"); None = the activation format.  The last block's CLS row stays 16-bit.
+        # attn_dtype="fp8": Q K^T and P V of the 11 full blocks on the block-scaled fp8 MFMA (OCP MX: e4m3 with one e8m0 scale
+        # per 32 elements, v_mfma_scale_f32_32x32x64_f8f6f4; BASELINE config "fp8 MFMA attention"); the attn.qkv GEMM writes the
+        # quantised operand images directly.  None = the activation format.  The last block's CLS row stays 16-bit.
         if attn_dtype not in (None, "fp8", act_dtype):
             raise ValueError("attn_dtype must be None, 'fp8' or equal to act_dtype")
         self.attn_fp8 = attn_dtype == "fp8"
@@ -132,6 +133,7 @@ class VideoAttention:
         self._tables = {}
         # range guard of the 16-bit storage (see attention_frames): sticky device flag + the pinned host copy of the last call
         self._flag, self._flag_pending, self._flag_hosts = None, [], []
+        self._mx_ws = {}          # rows -> zero-initialised workspace of the fp8 operand images (tails must stay zero)
 
     def __load_model(self, pretrained_weights):
         model = ViTSmall8Weights()
@@ -205,7 +207,13 @@ class VideoAttention:
         hid = torch.empty(rpad, MLP, device=dev, dtype=tdt)
         ws8 = None
         if self.attn_fp8:
-            ws8 = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", f, ntok, HEADS), device=dev, dtype=torch.uint8)
+            key = (rows, torch.cuda.current_stream().cuda_stream)
+            if key not in self._mx_ws:
+                self._mx_ws = {key: torch.zeros(_lib.query("maavss_vit_attn_mx_ws_bytes", rows), device=dev, dtype=torch.uint8)}
+            ws8 = self._mx_ws[key]
+            # rows of the last 64-row panel past the real ones take part in V's 32-token scale blocks: keep them finite
+            x[rows:].zero_()
+            att_o[rows:].zero_()
         call("maavss_vit_patchify", ptr(frames), ptr(a), f, h, w, dt, st)
         call("maavss_vit_gemm_stats", ptr(a), 192, ptr(wts["patch_w"]), None, ptr(table), ntok, ptr(x), DIM, rows, DIM, 192,
              EPI_F32_ROWTABLE, 0, 1.0, ptr(stats) if (self.ws_gemm and self.ws_ln_in) else None, dt, st)
@@ -215,7 +223,12 @@ class VideoAttention:
             # the last block only feeds the CLS-row attention (get_last_selfattention): q and k, not v -- the weight rows
             # are [q; k; v], so N = 2 DIM computes exactly those two thirds into the same [rows, 3 DIM] buffer
             nqkv = 2 * DIM if i == DEPTH - 1 else 3 * DIM
-            if self.ws_gemm:
+            mx_fused = self.attn_fp8 and self.ws_gemm and self.ws_ln_in and i < DEPTH - 1
+            if mx_fused:
+                # norm1 + qkv -> block-scaled fp8 operand images, no 16-bit qkv tensor and no quantisation pass
+                call("maavss_vit_ws_gemm_ln_mx", ptr(x), rpad, ptr(stats), ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
+                     ptr(b["qkv_b"]), ptr(ws8), rows, DIM, qs, dt, st)
+            elif self.ws_gemm:
                 if not self.ws_ln_in:
                     call("maavss_vit_layernorm", ptr(x), ptr(b["n1w"]), ptr(b["n1b"]), ptr(xn), rows, DIM, LN_EPS, dt, st)
                     call("maavss_vit_ws_gemm", ptr(xn), DIM, rpad, ptr(b["qkv_w"]), ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv,
@@ -235,7 +248,9 @@ class VideoAttention:
             if i == DEPTH - 1:
                 break
             if self.attn_fp8:
-                call("maavss_vit_attn_fp8", ptr(qkv), ptr(att_o), ptr(ws8), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
+                if not mx_fused:
+                    call("maavss_vit_qkv_mx", ptr(qkv), ptr(ws8), rows, 3 * DIM, dt, st)
+                call("maavss_vit_attn_mx", ptr(ws8), ptr(att_o), f, ntok, HEADS, DIM, dt, st)
             else:
                 call("maavss_vit_attn", ptr(qkv), ptr(att_o), f, ntok, HEADS, 3 * DIM, DIM, dt, st)
             if self.ws_gemm:

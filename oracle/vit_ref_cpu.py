@@ -229,3 +229,62 @@ def synthetic_frames(n, width, seed):
     mean = torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]
     std = torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]
     return (x - mean) / std
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Block-scaled fp8 (OCP MX) emulation for the config[4] attention path (maavss_amd/csrc/vit_mx.h, vit_attn_mx.hip):
+# e4m3 elements, one power-of-two (e8m0) scale per 32 elements along `dim`.  TEST INFRASTRUCTURE.
+# ----------------------------------------------------------------------------------------------------------------
+def mx_quantise(x, dim):
+    """Dequantised values of x after MX quantisation in blocks of 32 along `dim` (size a multiple of 32): scale = the smallest
+    power of two s with amax / s <= 448, computed with the kernel's integer formula on amax * (1/448) in float32."""
+    x = x.float().movedim(dim, -1)
+    shp = x.shape
+    xb = x.reshape(*shp[:-1], shp[-1] // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    bits = (amax * torch.tensor(1.0 / 448.0, dtype=torch.float32)).view(torch.int32)
+    e = ((bits + 0x7FFFFF) >> 23).clamp(max=253)
+    scale = torch.ldexp(torch.ones_like(amax), e - 127)
+    q = (xb / scale).to(torch.float8_e4m3fn).float() * scale
+    return q.reshape(shp).movedim(-1, dim)
+
+
+def attention_mx_ref(qkv, frames, ntok, heads=6):
+    """softmax(q k^T) v per (frame, head) with the operands quantised where vit_attn_mx_kernel's images are -- q, k per (token, 32 d);
+    v per (d, 32 GLOBAL token rows: blocks run over frame boundaries) -- and the flash loop of that kernel: key tiles of 64 starting
+    at the 32-aligned global row at or below the frame's first row, a running maximum that moves when a tile exceeds it by more
+    than 2^1 (first tile: rebased), P' = 2^7 exp2(s - m) rounded to e4m3 for the P V product while the row sum keeps the f32
+    values.  qkv [frames * ntok, 3 * heads * 64] with q pre-scaled to log2 units."""
+    rows, dim = frames * ntok, heads * 64
+    q, k, v = qkv.float().split(dim, 1)
+    q8, k8 = mx_quantise(q, 1), mx_quantise(k, 1)
+    pad = (-rows) % 32
+    vp = torch.cat([v, torch.zeros(pad, dim)]) if pad else v
+    v8 = mx_quantise(vp, 0)[:rows]
+    out = torch.empty(rows, dim)
+    thr, shift = 1.0, 7.0
+    for f in range(frames):
+        sl = slice(f * ntok, (f + 1) * ntok)
+        qf, kf, vf = [t[sl].view(ntok, heads, 64).transpose(0, 1) for t in (q8, k8, v8)]        # [heads, ntok, 64]
+        s_all = qf @ kf.transpose(-1, -2)
+        lead = (f * ntok) % 32
+        m = torch.zeros(heads, ntok, 1)
+        l = torch.zeros_like(m)
+        o = torch.zeros(heads, ntok, 64)
+        t0 = -lead
+        first = True
+        while t0 < ntok:
+            a, b = max(t0, 0), min(t0 + 64, ntok)
+            s = s_all[..., a:b] - m
+            mx = s.max(-1, keepdim=True).values
+            delta = mx if first else torch.where(mx > thr, mx, torch.zeros_like(mx))
+            alpha = torch.exp2(-delta)
+            m = m + delta
+            l, o = l * alpha, o * alpha
+            p = torch.exp2(s - delta + shift)
+            l = l + p.sum(-1, keepdim=True)
+            o = o + p.to(torch.float8_e4m3fn).float() @ vf[..., a:b, :]
+            t0 += 64
+            first = False
+        out[sl] = (o / l).transpose(0, 1).reshape(ntok, dim)
+    return out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of maavss_vit_attn on the GPU box (HIP events on the launch stream):
-    python scripts/attn_bench.py [--frames 512] [--ntok 785] [--dtype 0|2|3] [--iters 20]
+    python scripts/attn_bench.py [--frames 512] [--ntok 785] [--dtype 0|2|3|4] [--iters 20]
 Prints avg launch time, TFLOP/s on the useful 4*frames*heads*ntok^2*64 FLOPs and the fraction of the 2.5 PFLOP/s bf16 peak.
 MAAVSS_ATTN_VARIANT=1 selects the round-1 kernel (bf16) for A/B runs in separate processes."""
 import argparse
@@ -26,7 +26,8 @@ def main():
     a = ap.parse_args()
     rows = a.frames * a.ntok
     fp8 = a.dtype == 3            # fp8 attention on f16 qkv / out
-    tdt = {0: torch.bfloat16, 2: torch.float16, 3: torch.float16}[a.dtype]
+    mx = a.dtype == 4             # block-scaled fp8 (MX) attention kernel alone: the images are quantised once, outside the timing
+    tdt = {0: torch.bfloat16, 2: torch.float16, 3: torch.float16, 4: torch.float16}[a.dtype]
     g = torch.Generator(device="cuda").manual_seed(1)
     qkv = torch.randn(rows, 1152, device="cuda", generator=g)
     qkv[:, :384] *= 0.125 * 1.4426950408889634
@@ -35,9 +36,12 @@ def main():
     qkv = qkv.to(tdt)
     out = torch.empty(rows, 384, device="cuda", dtype=tdt)
     st = _lib.stream_ptr()
-    if fp8:
-        ws = torch.empty(_lib.query("maavss_vit_attn_fp8_ws_bytes", a.frames, a.ntok, 6), device="cuda", dtype=torch.uint8)
-        run = lambda: _lib.call("maavss_vit_attn_fp8", qkv.data_ptr(), out.data_ptr(), ws.data_ptr(), a.frames, a.ntok, 6, 1152, 384, 2, st)
+    if mx:
+        ws = torch.empty(_lib.query("maavss_vit_attn_mx_ws_bytes", rows), device="cuda", dtype=torch.uint8)
+        _lib.call("maavss_vit_qkv_mx", qkv.data_ptr(), ws.data_ptr(), rows, 1152, 2, st)
+        run = lambda: _lib.call("maavss_vit_attn_mx", ws.data_ptr(), out.data_ptr(), a.frames, a.ntok, 6, 384, 2, st)
+    elif fp8:
+        raise SystemExit("--dtype 3 (round 2's non-scaled fp8 kernel) was removed in round 3: use --dtype 4 (block-scaled fp8)")
     else:
         run = lambda: _lib.call("maavss_vit_attn", qkv.data_ptr(), out.data_ptr(), a.frames, a.ntok, 6, 1152, 384, a.dtype, st)
     for _ in range(5):

@@ -105,7 +105,10 @@ def test_16bit_configuration_against_emulating_and_fp32_oracles(tag, batch, fram
     _grad_report(model, emu, twin, tag)
 
 
-@pytest.mark.parametrize("act", ["f16", "bf16"])
+FP8_MASK_MSE_BOUND = 1e-2      # stated bound for attn_dtype="fp8" (measured value printed and in DESIGN.md)
+
+
+@pytest.mark.parametrize("act", ["f16", "bf16", "fp8"])
 def test_end_to_end_frames_to_mask_with_the_vit_in_the_loop(act):
     """frames -> attention frames (16-bit HIP ViT) -> AVSE (16-bit HIP) vs the all-fp32 oracle chain on the pinned P shape
     (av_dataset.py:321-333 -> train_avse_frames.py:164-168).  With IEEE-half storage in the extractor (the default) the chain
@@ -116,7 +119,10 @@ def test_end_to_end_frames_to_mask_with_the_vit_in_the_loop(act):
     b, t, w, hpf = 2, 8, 256, 8
     model, twin, (x_a, _, y_a, _) = _build(b, t, w, 512, 43, precise=False, spatial_match="exact")
     sd = vref.seeded_vit_state(3)
-    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act)
+    if act == "fp8":     # BASELINE config[4]: block-scaled fp8 Q K^T / P V inside the IEEE-half extractor
+        va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype="f16", attn_dtype="fp8")
+    else:
+        va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act)
     va.load_state_dict(sd)
     frames = vref.synthetic_frames(b * t, w, 9)
     with torch.no_grad():
@@ -130,7 +136,11 @@ def test_end_to_end_frames_to_mask_with_the_vit_in_the_loop(act):
     mse = float(((a.detach().cpu() - a_ref.detach()) ** 2).mean())
     print(f"[parity] end to end ({act} ViT): attention maps max|err| {map_err.max().item():.3e} mean {map_err.mean().item():.3e}; "
           f"mask-MSE {mse:.3e}; |dloss| {abs(loss.item() - loss_ref.item()):.3e} (loss {loss_ref.item():.5f})")
-    if act == "f16":
+    if act == "fp8":
+        # e4m3 operands (3 mantissa bits) cannot meet the 1e-5 target: the mode is selectable (config[4]), never the default
+        assert mse <= FP8_MASK_MSE_BOUND, mse
+        assert abs(loss.item() - loss_ref.item()) <= 5e-3
+    elif act == "f16":
         assert mse <= 1e-5, mse                                   # BASELINE.json: mask MSE within 1e-5 of the reference
         assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-5      # same bound as the benched-shape test above
     else:
