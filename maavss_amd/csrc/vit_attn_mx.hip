@@ -35,6 +35,16 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 __device__ __forceinline__ f32x16 mfma_mx(const i32x8& a, const i32x8& b, const f32x16& c, int scale_a, int scale_b) {
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, scale_a, 0, scale_b);
 }
+// D = A B + C with C and D in DIFFERENT registers (C = the persistent -m_run block): as a builtin hipcc ties D to C for the second
+// instruction of a tile and copies the 16 C registers first (8 v_mov_b64 per tile).  Inline asm: the compiler inserts the waitcnt
+// for the LDS-loaded operands, but no MFMA hazard padding -- the operands here come from LDS reads or are long-lived, and the
+// readers of D sit behind the explicit s_nop block of the softmax.
+__device__ __forceinline__ f32x16 mfma_mx_c(const i32x8& a, const i32x8& b, const f32x16& c, int scale_a, int scale_b) {
+  f32x16 d;
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]"
+               : "=&v"(d) : "v"(a), "v"(b), "v"(c), "v"(scale_a), "v"(scale_b));
+  return d;
+}
 __device__ __forceinline__ i32x8 cat16(uint4 lo, uint4 hi) {
   i32x8 v;
   v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w;
@@ -77,7 +87,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-  float mrow = 0.f, lrow = 0.f;
+  float mrow = 0.f;
+  // Row sum l = sum_k P'[k][q] on the MATRIX pipe: one more instruction per tile with an all-ones A operand (every output row is
+  // the sum; the loop is bound by vector issue -- PMC: 52 VALU instructions per MFMA, matrix pipe 19 % busy -- and the 32 adds
+  // of the row sum were a third of the non-transcendental VALU work).  It sums the e4m3-ROUNDED P', the very weights of O.
+  f32x16 lacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+  i32x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;     // e4m3 1.0
   f32x16 cinit;                          // -m_run (+ the P' shift) in all 16 registers: the C operand of the Q K^T instructions
 #pragma unroll
   for (int e = 0; e < 16; ++e) cinit[e] = MXA_PSHIFT;
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const unsigned char* kp = kt_base + t * 32 * 64 + koff0;
       const i32x8 fk = cat16(*reinterpret_cast<const uint4*>(kp), *reinterpret_cast<const uint4*>(kp + ((koff0 & 32) ? -32 : 32)));
       const int sk = Scl[buf][h * 64 + 32 * t + kkey];
-      s[t] = mfma_mx(fk, fq, cinit, sk, sq);
+      s[t] = mfma_mx_c(fk, fq, cinit, sk, sq);
     }
     __builtin_amdgcn_s_setprio(0);
     // wait states between the matrix write and the VALU reads inside the asm max chain (hipcc does not look into asm)
@@ -174,7 +193,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       mrow += delta;
 #pragma unroll
       for (int e = 0; e < 16; ++e) cinit[e] = MXA_PSHIFT - mrow;
-      lrow *= alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -185,20 +205,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int e = 0; e < 16; ++e) s[t][e] -= delta;
     }
     i32x8 fp;
-    {
-      float sum = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float p = __builtin_amdgcn_exp2f(s[t][e]);
-          s[t][e] = p;
-          sum += p;
-        }
+      for (int e = 0; e < 16; ++e) s[t][e] = __builtin_amdgcn_exp2f(s[t][e]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fp[4 * t + g] = (int)mx_cvt4(s[t][4 * g], s[t][4 * g + 1], s[t][4 * g + 2], s[t][4 * g + 3]);
-      }
-      lrow += sum;
+      for (int g = 0; g < 4; ++g) fp[4 * t + g] = (int)mx_cvt4(s[t][4 * g], s[t][4 * g + 1], s[t][4 * g + 2], s[t][4 * g + 3]);
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int sv = Scl[buf][128 + h * 64 + 32 * db + r];
       o[db] = mfma_mx(fv, fp, o[db], sv, 127);
     }
+    lacc = mfma_mx(ones, fp, lacc, 127, 127);
     __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < ntiles - 1; ++kt) {
@@ -222,9 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (wave_active) tile(ntiles - 1);
   // ---- normalise and store: lane (q = r, h) holds d = 32 db + 8 g + 4 h + (0..3) in registers 4g..4g+3 of o[db]
   {
-    float la, lb;
-    lane_swap32(lrow, la, lb);
-    const float inv = 1.f / (la + lb);
+    const float inv = 1.f / lacc[0];            // every row of the ones-product holds the full sum over the keys
     const int qr = q0 + r;
     if (qr < ntok) {
       bf16_t* op = out + (row0 + qr) * ld_out + head * MXA_D + 4 * h;

@@ -57,7 +57,9 @@ __device__ __forceinline__ unsigned mx_scale_byte(float amax, float& inv) {
   return e;
 }
 __device__ __forceinline__ unsigned mx_cvt4(float a, float b, float c, float d) {
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);   // bytes 0, 1
+  int w;
+  asm volatile("" : "=v"(w));                                // both halves are written below: no zero-initialisation needed
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);       // bytes 0, 1
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);        // bytes 2, 3
   return (unsigned)w;
 }

@@ -253,8 +253,8 @@ def attention_mx_ref(qkv, frames, ntok, heads=6):
     """softmax(q k^T) v per (frame, head) with the operands quantised where vit_attn_mx_kernel's images are -- q, k per (token, 32 d);
     v per (d, 32 GLOBAL token rows: blocks run over frame boundaries) -- and the flash loop of that kernel: key tiles of 64 starting
     at the 32-aligned global row at or below the frame's first row, a running maximum that moves when a tile exceeds it by more
-    than 2^1 (first tile: rebased), P' = 2^7 exp2(s - m) rounded to e4m3 for the P V product while the row sum keeps the f32
-    values.  qkv [frames * ntok, 3 * heads * 64] with q pre-scaled to log2 units."""
+    than 2^1 (first tile: rebased), P' = 2^7 exp2(s - m) rounded to e4m3 for the P V product AND for the row sum (the very
+    weights of O).  qkv [frames * ntok, 3 * heads * 64] with q pre-scaled to log2 units."""
     rows, dim = frames * ntok, heads * 64
     q, k, v = qkv.float().split(dim, 1)
     q8, k8 = mx_quantise(q, 1), mx_quantise(k, 1)
@@ -281,9 +281,9 @@ def attention_mx_ref(qkv, frames, ntok, heads=6):
             alpha = torch.exp2(-delta)
             m = m + delta
             l, o = l * alpha, o * alpha
-            p = torch.exp2(s - delta + shift)
-            l = l + p.sum(-1, keepdim=True)
-            o = o + p.to(torch.float8_e4m3fn).float() @ vf[..., a:b, :]
+            p8 = torch.exp2(s - delta + shift).to(torch.float8_e4m3fn).float()
+            l = l + p8.sum(-1, keepdim=True)         # the kernel sums the rounded weights (a ones-row on the matrix pipe)
+            o = o + p8 @ vf[..., a:b, :]
             t0 += 64
             first = False
         out[sl] = (o / l).transpose(0, 1).reshape(ntok, dim)
