@@ -3,7 +3,9 @@
 #   scripts/round_profiles.sh <tag>
 # writes into gpurun_out/ (copy the summaries into profiles/ afterwards):
 #   <tag>_bench.json               the default bench.py line (with cpu_baseline)
-#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command (3 timed steps)
+#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of bench.py --pipeline off (one stream: a kernel's duration is its
+#                                  own, which is what the bench line's `roofline` reports from its one-stream pass)
+#   <tag>_bench_kernel_stats_two_streams.csv   the same for the default two-stream run (kernels share the chip: longer launches)
 #   <tag>_pmc_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE per kernel launch, separate --pmc passes, FETCH doubled
 #                                  (gfx950 tallies 128-B requests at 64 B; MI355X_MICROARCH.md, HBM section)
 set -e
@@ -14,14 +16,16 @@ mkdir -p $OUT
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_$TAG.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $R/bench.py --pipeline off --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof2_$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $R/bench.py --pipeline off --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $R/bench.py --pipeline off --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_$TAG.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, json, collections, shutil
 out = "$OUT"; tag = "$TAG"
 shutil.copy(glob.glob(f"{out}/prof_{tag}/**/*kernel_stats.csv", recursive=True)[0], f"{out}/{tag}_bench_kernel_stats.csv")
+shutil.copy(glob.glob(f"{out}/prof2_{tag}/**/*kernel_stats.csv", recursive=True)[0], f"{out}/{tag}_bench_kernel_stats_two_streams.csv")
 def per_kernel(d, name):
     f = glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True)[0]
     tot, cnt = collections.defaultdict(float), collections.Counter()
