@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true", help="global-batch BatchNorm statistics over the ranks (N > 1)")
     ap.add_argument("--attn-dtype", choices=["same", "fp8"], default="same",
                     help="fp8: Q K^T / P V of the ViT blocks on fp8 (e4m3) MFMA (BASELINE config 'fp8 MFMA attention'); the headline line uses 'same'")
+    ap.add_argument("--grad-wire", choices=["f32", "bf16"], default="f32",
+                    help="wire format of the gradient all-reduce at N > 1 (bf16: half the xGMI bytes, bf16 sum over the ranks)")
     ap.add_argument("--pipeline", choices=["on", "off"], default="on",
                     help="on: attention-frame extraction + STFT of batch i+1 on a second HIP stream under the training step of batch i "
                          "(maavss_amd.ClipPipeline; the reference's data path has no dependency on the optimizer step); off: one stream")
@@ -181,7 +183,8 @@ def main():
                                                   spatial_match="adaptive")
         spatial = "adaptive"
     model = model.to(dev).train()
-    step_fn = maavss_amd.TrainStep(model, lr=1e-5, loss_coeff=0.001, num_seq=1, sync_bn=args.sync_bn)
+    step_fn = maavss_amd.TrainStep(model, lr=1e-5, loss_coeff=0.001, num_seq=1, sync_bn=args.sync_bn,
+                                   grad_wire_dtype=None if args.grad_wire == "f32" else args.grad_wire)
     mid = t // 2
     attn = torch.empty(b * t, 1, w, w, device=dev, dtype=torch.float32)
 
@@ -351,8 +354,9 @@ def main():
             per = a0[1] * (4.0 * a0[2] + 2 * 2.0 * a0[7] * a0[8] * 4.0)
             stage_row("maavss_stft_fwd", bytes_=per * summ["maavss_stft_fwd"]["calls"])
             if "stft_fwd" in stages:
-                stages["stft_fwd"]["note"] = ("one launch per step over B*(T_a+1) frames: at B=32 that is ~4k waves = one wave round of "
-                                              "the chip, so the figure is launch/latency-bound, not a bandwidth limit (DESIGN.md 9)")
+                stages["stft_fwd"]["note"] = ("one launch per step over B*T_a frames: at B=32 that is ~4k waves = one wave round of the chip "
+                                              "(launch/latency-bound); the kernel reaches 1.2 TB/s at B=256 and 1.4 TB/s at B=8192 "
+                                              "(profiles/r3_stft_bench.json): one wave per frame is bound by its FFT + Philox vector work, DESIGN.md 9")
         if "maavss_adam_step" in summ:     # p, g, m, v read + p, m, v written: 28 B per parameter
             stage_row("maavss_adam_step", bytes_=sum(28.0 * a[4] for a in summ["maavss_adam_step"]["args"]))
         # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
@@ -410,7 +414,7 @@ def main():
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
                        "parallelism": f"dp{world}", "streams": "2 (extraction of batch i+1 under the training step of batch i)" if pipe is not None else "1", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
                        "vit": args.vit_dtype, "vit_attention": "block-scaled fp8 (MX e4m3, e8m0 scale per 32; f32 accumulate -- wider than the config's bf16)" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
-                       "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank",
+                       "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank", "grad_all_reduce": f"{args.grad_wire} wire, per-module buckets in backward order",
                        "loss": loss_val},
             "roofline": roofline,
             "stages": stages,

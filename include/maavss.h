@@ -226,6 +226,11 @@ int maavss_mse_pair(const float* a_pred, const float* a_tgt, int64_t na, const f
                     void* stream);
 int maavss_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int64_t step, float grad_scale, void* stream);
+/* K18 helper, EXTENSION (the reference is single-device): bf16 wire format of the data-parallel gradient all-reduce -- a bucket of
+ * the flat f32 gradient buffer is rounded to bf16 (round-to-nearest-even) for the collective and widened back into the f32 master
+ * buffer afterwards (trainer.GradSync(wire_dtype="bf16")).  n a multiple of 8, buffers 16-byte aligned. */
+int maavss_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int maavss_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 
 /* ---- K1-K6 DINO ViT-S/8 attention-frame extractor ------------------------------------------------
  * What VideoAttention._inference (video_attention.py:38-103) obtains from dino's

@@ -192,3 +192,37 @@ extern "C" int maavss_leaky_bwd(const float* dout, const float* out, float* dz, 
   MAAVSS_LAUNCH_CHECK("leaky_bwd_kernel");
   return MAAVSS_OK;
 }
+
+// ---- bf16 wire format of the gradient all-reduce (K18, optional; SURVEY.md 5: "bf16 gradient compression"): the flat f32 gradient
+// bucket is rounded to bf16 for the collective and widened back into the f32 master buffer afterwards.  8 elements per thread.
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    reinterpret_cast<uint4*>(dst)[i] = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 u = reinterpret_cast<const uint4*>(src)[i];
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                                            __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+  }
+}
+extern "C" int maavss_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  MAAVSS_CHECK_ARG(src && dst && n > 0 && n % 8 == 0, "f32_to_bf16: n must be a positive multiple of 8");
+  MAAVSS_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "f32_to_bf16: 16-byte aligned buffers");
+  const int64_t n8 = n / 8;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(n8 / 256 + 1 > 4096 ? 4096 : n8 / 256 + 1)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8);
+  MAAVSS_LAUNCH_CHECK("f32_to_bf16_kernel");
+  return MAAVSS_OK;
+}
+extern "C" int maavss_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  MAAVSS_CHECK_ARG(src && dst && n > 0 && n % 8 == 0, "bf16_to_f32: n must be a positive multiple of 8");
+  MAAVSS_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "bf16_to_f32: 16-byte aligned buffers");
+  const int64_t n8 = n / 8;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)(n8 / 256 + 1 > 4096 ? 4096 : n8 / 256 + 1)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n8);
+  MAAVSS_LAUNCH_CHECK("bf16_to_f32_kernel");
+  return MAAVSS_OK;
+}

@@ -485,3 +485,16 @@ def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0
     _f32(p, g, m, v)
     call("maavss_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
          float(eps), int(step), float(grad_scale), stream_ptr())
+
+
+def f32_to_bf16(src, dst):
+    """bf16 wire format of the gradient all-reduce: dst (bf16) = round(src (f32)); length a multiple of 8."""
+    _lib.require_cuda(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    call("maavss_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+
+
+def bf16_to_f32(src, dst):
+    _lib.require_cuda(src, dst)
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.numel() == dst.numel()
+    call("maavss_bf16_to_f32", ptr(src), ptr(dst), src.numel(), stream_ptr())

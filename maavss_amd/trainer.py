@@ -212,8 +212,14 @@ class GradSync:
     frozen parameter's old gradient is never summed over the ranks step after step.
     `start_fusion()` (round-1/2 interface) launches whatever is left of the fusion segment in one go."""
 
-    def __init__(self, grads, fusion_end, process_group=None, flat=None):
+    def __init__(self, grads, fusion_end, process_group=None, flat=None, wire_dtype=None):
         import torch.distributed as dist
+        if wire_dtype not in (None, "f32", "bf16"):
+            raise ValueError("wire_dtype must be None / 'f32' or 'bf16'")
+        # "bf16": every bucket is rounded to bf16 for the collective (half the xGMI bytes; the sum over the ranks is then a bf16 sum)
+        # and widened back into the f32 master buffer in finish().  Device tensors only: the conversion is a HIP kernel.
+        self.wire_bf16 = wire_dtype == "bf16"
+        self._wire = None
         self.dist = dist
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
@@ -281,8 +287,17 @@ class GradSync:
                     if n not in keep:
                         self.grads[lo:min(hi, b["hi"])].zero_()      # stale gradient of a frozen parameter
         self.launch_log.append(b["key"])
-        self._pending.append(self.dist.all_reduce(self.grads[b["lo"]:b["hi"]], op=self.dist.ReduceOp.SUM, group=self.group,
-                                                  async_op=True))
+        if self.wire_bf16:
+            if self._wire is None:
+                self._wire = torch.empty(self.grads.numel(), device=self.grads.device, dtype=torch.bfloat16)
+            lo, hi = b["lo"], (b["hi"] + 7) // 8 * 8
+            hi = min(hi, self.grads.numel() // 8 * 8)
+            ops.f32_to_bf16(self.grads[lo:hi], self._wire[lo:hi])
+            work = self.dist.all_reduce(self._wire[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, lo, hi))
+            return
+        self._pending.append((self.dist.all_reduce(self.grads[b["lo"]:b["hi"]], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True), None, None))
 
     def grad_ready(self, name):
         """The gradient of `name` has been enqueued on the current stream; launches its bucket when that completes it."""
@@ -302,8 +317,10 @@ class GradSync:
         self.start_fusion()
         for i, b in enumerate(self.buckets):
             self._launch(i)
-        for w in self._pending:
+        for w, lo, hi in self._pending:
             w.wait()
+            if lo is not None:
+                ops.bf16_to_f32(self._wire[lo:hi], self.grads[lo:hi])
         self._pending = []
         self._expected, self._ready, self._launched = None, set(), set()
 
@@ -319,12 +336,12 @@ class TrainStep:
     """One optimizer step of the fusion network, autograd-free (see module docstring)."""
 
     def __init__(self, model, lr=1e-5, loss_coeff=0.001, num_seq=1, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, sync_bn=False):
+                 process_group=None, sync_bn=False, grad_wire_dtype=None):
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.loss_coeff, self.num_seq = loss_coeff, num_seq
-        self.sync = GradSync(self.flat.grads, self.flat.fusion_end, process_group, flat=self.flat)
+        self.sync = GradSync(self.flat.grads, self.flat.fusion_end, process_group, flat=self.flat, wire_dtype=grad_wire_dtype)
         # replicas start identical: rank 0's weights (one flat buffer) and BatchNorm buffers, like DDP's constructor
         self.sync.broadcast([self.flat.params] + [b for _, b in model.named_buffers()])
         if sync_bn and self.sync.enabled:

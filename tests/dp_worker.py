@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--adam", type=int, default=0)
     ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--wire", default="f32")
     ap.add_argument("--freeze-enc-after", type=int, default=-1, help="toggle_enc_grads(False) before this step index")
     args = ap.parse_args()
     import torch
@@ -38,7 +39,8 @@ def main():
     # rank 0 holds the seeded weights, the other ranks start from garbage: the constructor's broadcast must repair that
     model.load_state_dict(orc.seeded_state_dict(twin, 31 if rank == 0 else 99), strict=True)
     model = model.to("cuda").train()
-    step = maavss_amd.TrainStep(model, lr=1e-3, loss_coeff=0.001, num_seq=1, sync_bn=bool(args.sync_bn))
+    step = maavss_amd.TrainStep(model, lr=1e-3, loss_coeff=0.001, num_seq=1, sync_bn=bool(args.sync_bn),
+                                grad_wire_dtype=None if args.wire == "f32" else args.wire)
     x_a, x_v, y_a, y_v = orc.synthetic_batch(args.batch, t, w, t_a, n_bins, hpf, 32)
     lo, hi = maavss_amd.shard_batch(args.batch, rank, world)
     logs = []

@@ -114,3 +114,21 @@ def test_three_adam_steps_leave_the_replicas_bit_identical_and_buckets_launch_in
         assert r["launch_logs"][0] == ["a_fc1", "v_fc1", "fc2", "fc1", "lstm", "encoders"], r["launch_logs"][0]
         assert r["launch_logs"][2] == ["a_fc1", "v_fc1", "fc2", "fc1", "lstm"], r["launch_logs"][2]
     assert ranks[0]["enc_grad_absmax"] == ranks[1]["enc_grad_absmax"] and ranks[0]["enc_grad_absmax"] < 1e6
+
+
+def test_bf16_wire_format_of_the_gradient_all_reduce(tmp_path):
+    """GradSync(wire_dtype="bf16") (bf16 gradient compression): each bucket is rounded to bf16 by a HIP kernel,
+    all-reduced, and widened back into the f32 master buffer.  Both ranks end with the same gradients, within bf16 rounding
+    (of the operands and of the two-rank sum) of the f32-wire result."""
+    f32 = _run_ranks(tmp_path, sync_bn=True)
+    b16 = _run_ranks(tmp_path, sync_bn=True, extra=("--wire", "bf16"))
+    worst = 0.0
+    for n, g in f32[0]["grads"].items():
+        if n.startswith("stft_decoder."):
+            continue
+        assert torch.equal(b16[0]["grads"][n], b16[1]["grads"][n]), n
+        err = (b16[0]["grads"][n] - g).norm().item() / (g.norm().item() + 1e-30)
+        worst = max(worst, err)
+        assert err <= 6e-3, (n, err)            # bf16: 2^-9 per operand and per sum, rms over the tensor
+        assert (b16[0]["grads"][n] - g).abs().max().item() <= 2.0 ** -7 * g.abs().max().item() + 1e-12, n
+    print(f"[dp] bf16 wire vs f32 wire: worst gradient tensor relative L2 {worst:.2e}")
