@@ -502,3 +502,34 @@ def test_half_storage_overflow_is_detected_and_bf16_survives():
     # and an in-range checkpoint passes the check untouched
     va.load_state_dict(vref.seeded_vit_state(3))
     assert torch.isfinite(va.attention_frames(fr, clip_frames=4)).all()
+
+
+def test_half_extractor_on_a_checkpoint_with_large_activations():
+    """the IEEE-half default had only seen trunc_normal(0.02) weights.  No DINO checkpoint exists offline, so
+    this builds one with the magnitudes real ViTs show: the residual-writing layers (attn.proj, mlp.fc2) of the first three blocks
+    scaled 40x -- residual-stream values of several hundred ("massive activations"), peaked CLS attention (max ~0.9).  The half
+    extractor must stay inside its range (guard silent), stay close to the fp32 oracle on the maps, and be closer than bf16 storage
+    (fp32's range, 8 mantissa bits) is.  (Scaling every Linear 4x saturates the softmax to one-hot rows: the maps then flip between
+    keys under any rounding, the fp32 emulations included -- not a usable probe.)"""
+    import maavss_amd
+    from oracle import vit_ref_cpu as vref
+    sd = vref.seeded_vit_state(5)
+    for k in list(sd):
+        if k.startswith("blocks.") and k.endswith(".weight") and (".attn.proj." in k or ".mlp.fc2." in k) and int(k.split(".")[1]) < 3:
+            sd[k] = sd[k] * 40.0
+    fr = vref.synthetic_frames(2, 224, 7)
+    with torch.no_grad():
+        want = vref.inference_ref(sd, fr)
+        hidden = torch.stack(vref.get_last_selfattention(sd, fr, return_hidden=True)[1])
+    errs = {}
+    for act in ("f16", "bf16"):
+        va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act)
+        va.load_state_dict(sd)
+        got = va._inference(fr)                    # raises MaavssError if the range guard fires
+        assert torch.isfinite(got).all()
+        errs[act] = ((got - want).abs().max().item(), (got - want).abs().mean().item())
+    norm = f", residual-stream |x| max {hidden.abs().max().item():.0f}"
+    print(f"[range] scaled checkpoint{norm}: maps vs fp32 oracle f16 max {errs['f16'][0]:.3e} mean {errs['f16'][1]:.3e}; "
+          f"bf16 max {errs['bf16'][0]:.3e} mean {errs['bf16'][1]:.3e}")
+    assert errs["f16"][0] <= 5e-2 and errs["f16"][1] <= 6e-3
+    assert errs["f16"][1] < errs["bf16"][1]
