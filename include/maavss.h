@@ -79,7 +79,9 @@ int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk);
 int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
                         int c_in, int c_out, int pad, int beta, int precise, int dy16, void* stream);
 /* first layer (C_in = 1, pad 2): x [B][T][H][W], w [16][1][3][5][5], w16_ws 1200 floats scratch,
- * y [B][T][H][W][16]; stat_partials as above; wgrad ws = nchunk*1200 floats. */
+ * y [B][T][H][W][16]; stat_partials [maavss_conv3d_c1_fwd_nparts(...)][2][16] (one row per workgroup: the MFMA form walks
+ * 8 tiles per workgroup); wgrad ws = nchunk*1200 floats. */
+int64_t maavss_conv3d_c1_fwd_nparts(int B, int T, int H, int W, int precise);
 int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B, int T,
                          int H, int W, int precise /* 1: exact-f32 VALU convolution; 2: IEEE-half operands on the MFMA
                          (25 taps of a kd plane = one 32-deep step), f32 accumulation */, void* stream);

@@ -669,22 +669,24 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
 // (g, j), position) sits in 8 address registers computed once and whose (kd, row) part is an immediate -- no address
 // arithmetic in the loop.  12 MFMAs per wave and tile instead of 300 packed FMAs per lane: the f32 VALU kernel ran at 62 of the
 // 157 TFLOP/s vector peak (0.99 ms per step); this one is bound by its 1.6 GB output.
+// Round 3: a workgroup walks C1_TPW consecutive tiles (tx fastest): the weight fragments and tap addresses are set up once,
+// the next tile's halo is requested before this tile's MFMAs and written to the other LDS buffer after them, and the BatchNorm
+// partial sums are reduced once per workgroup (one row of `stat_partials` per workgroup).  With one tile per workgroup (100 352
+// workgroups at 32 x 16 x 224^2) each lived ~14 us, most of it the prologue's dependent global loads.
+#define C1_TPW 8
 __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  float* __restrict__ y, float* __restrict__ stat_partials,
                                                                  int n_bt, int T, int H, int W) {
-  __shared__ __attribute__((aligned(16))) unsigned short halo[3][20][24];
+  __shared__ __attribute__((aligned(16))) unsigned short halo[2][3][20][24];
   __shared__ float red[4][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, g = lane >> 4;
-  const TileId tile = xcd_tile((W + 15) / 16, (H + 15) / 16, (int64_t)((W + 15) / 16) * ((H + 15) / 16) * n_bt);
-  if (!tile.valid) return;
-  const int x0 = tile.tx * 16, y0 = tile.ty * 16, bt = tile.bt, t = bt % T;
-  for (int i = tid; i < 1200; i += 256) {
-    const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
-    const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
-    float v = 0.f;
-    if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(bt + kd - 1) * H + iy) * W + ix];
-    halo[kd][r][c] = Mma<MODE_F16>::cvt(v);
-  }
+  const int nx = (W + 15) / 16, ny = (H + 15) / 16;
+  const int64_t total = (int64_t)nx * ny * n_bt, nsuper = (total + C1_TPW - 1) / C1_TPW;
+  const int64_t per = (nsuper + 7) / 8;
+  const int64_t sup = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD k walks the k-th eighth of the tile list
+  if ((int64_t)(blockIdx.x >> 3) >= per || sup >= nsuper) return;
+  const int64_t lin0 = sup * C1_TPW;
+  const int ntile = (int)((total - lin0) < C1_TPW ? (total - lin0) : C1_TPW);
   // weight fragments (B operand): lane (co = l16, g) holds W[co][kd][k = 8 g + j], j = 0..7, zero for k >= 25
   bf16x8 fb[3];
 #pragma unroll
@@ -707,42 +709,73 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __
     const int kh = k / 5, kw = k % 5;
     addr[j] = (unsigned)(((4 * wv + kh) * 24 + l16 + kw) * 2);      // byte offset inside the halo image
   }
-  __syncthreads();
-  f32x4 acc[4];
+  // halo staging through registers: 1200 elements per tile, 5 per thread (the last round: 176 threads)
+  float hreg[5];
+  auto fetch = [&](int64_t lin) __attribute__((always_inline)) {
+    const int tx = (int)(lin % nx), ty = (int)((lin / nx) % ny), bt = (int)(lin / ((int64_t)nx * ny)), t = bt % T;
+    const int x0 = tx * 16, y0 = ty * 16;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // one M-tile (row i) x one kd plane: the (kd, row) displacement is an instruction immediate
-  auto step = [&](auto kd_c, auto i_c) __attribute__((always_inline)) {
-    constexpr int kd = decltype(kd_c)::value, i = decltype(i_c)::value;
-    constexpr int off = (kd * 20 + i) * 24 * 2;       // bytes: kd plane 20 x 24 halves, row 24 halves
-    // eight zero-extending 16-bit reads (per-lane part of the address in addr[], (kd, row) part a compile-time displacement),
-    // paired into the four fragment registers
-    const char* hb = reinterpret_cast<const char*>(&halo[0][0][0]) + off;
-    const unsigned e0 = *reinterpret_cast<const unsigned short*>(hb + addr[0]), e1 = *reinterpret_cast<const unsigned short*>(hb + addr[1]);
-    const unsigned e2 = *reinterpret_cast<const unsigned short*>(hb + addr[2]), e3 = *reinterpret_cast<const unsigned short*>(hb + addr[3]);
-    const unsigned e4 = *reinterpret_cast<const unsigned short*>(hb + addr[4]), e5 = *reinterpret_cast<const unsigned short*>(hb + addr[5]);
-    const unsigned e6 = *reinterpret_cast<const unsigned short*>(hb + addr[6]), e7 = *reinterpret_cast<const unsigned short*>(hb + addr[7]);
-    const unsigned a0 = e0 | (e1 << 16), a1 = e2 | (e3 << 16), a2 = e4 | (e5 << 16), a3 = e6 | (e7 << 16);
-    const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
-    Mma<MODE_F16>::mma(acc[i], fb[kd], fa);     // D[channel][position]: a lane ends up with 4 consecutive channels of one position
-  };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
-  step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
-  step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
-  // ---- epilogue: lane holds channels 4 g + (0..3) of position (row 4 wv + i, column l16): 16-byte stores, the 16 lanes of a row
-  // group write 16 consecutive positions = 1 KiB contiguous per store instruction (with positions on the MFMA rows a lane held
-  // one channel of four positions and every store scattered 4-byte pieces)
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int oy = y0 + 4 * wv + i, ox = x0 + l16;
-    if (oy < H && ox < W) {
-      *reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16 + 4 * g) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[r] += acc[i][r]; s2[r] += acc[i][r] * acc[i][r]; }
+    for (int j = 0; j < 5; ++j) {
+      const int i = tid + j * 256;
+      const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
+      const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
+      hreg[j] = 0.f;
+      if (i < 1200 && tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) hreg[j] = x[((int64_t)(bt + kd - 1) * H + iy) * W + ix];
     }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int i = tid + j * 256;
+      if (i < 1200) (&halo[buf][0][0][0])[i / 400 * 480 + (i % 400) / 20 * 24 + i % 20] = Mma<MODE_F16>::cvt(hreg[j]);
+    }
+  };
+  fetch(lin0);
+  stash(0);
+  __syncthreads();
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int64_t lin = lin0 + kt;
+    const int tx = (int)(lin % nx), ty = (int)((lin / nx) % ny), bt = (int)(lin / ((int64_t)nx * ny));
+    const int x0 = tx * 16, y0 = ty * 16;
+    if (kt + 1 < ntile) fetch(lin + 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* hbuf = reinterpret_cast<const char*>(&halo[kt & 1][0][0][0]);
+    // one M-tile (row i) x one kd plane: the (kd, row) displacement is an instruction immediate
+    auto step = [&](auto kd_c, auto i_c) __attribute__((always_inline)) {
+      constexpr int kd = decltype(kd_c)::value, i = decltype(i_c)::value;
+      constexpr int off = (kd * 20 + i) * 24 * 2;       // bytes: kd plane 20 x 24 halves, row 24 halves
+      // eight zero-extending 16-bit reads (per-lane part of the address in addr[], (kd, row) part a compile-time displacement),
+      // paired into the four fragment registers
+      const char* hb = hbuf + off;
+      const unsigned e0 = *reinterpret_cast<const unsigned short*>(hb + addr[0]), e1 = *reinterpret_cast<const unsigned short*>(hb + addr[1]);
+      const unsigned e2 = *reinterpret_cast<const unsigned short*>(hb + addr[2]), e3 = *reinterpret_cast<const unsigned short*>(hb + addr[3]);
+      const unsigned e4 = *reinterpret_cast<const unsigned short*>(hb + addr[4]), e5 = *reinterpret_cast<const unsigned short*>(hb + addr[5]);
+      const unsigned e6 = *reinterpret_cast<const unsigned short*>(hb + addr[6]), e7 = *reinterpret_cast<const unsigned short*>(hb + addr[7]);
+      const unsigned a0 = e0 | (e1 << 16), a1 = e2 | (e3 << 16), a2 = e4 | (e5 << 16), a3 = e6 | (e7 << 16);
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
+      Mma<MODE_F16>::mma(acc[i], fb[kd], fa);     // D[channel][position]: a lane ends up with 4 consecutive channels of one position
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
+    step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
+    step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
+    // ---- lane holds channels 4 g + (0..3) of position (row 4 wv + i, column l16): 16-byte stores, the 16 lanes of a row group
+    // write 16 consecutive positions = 1 KiB contiguous per store instruction
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = y0 + 4 * wv + i, ox = x0 + l16;
+      if (oy < H && ox < W) {
+        *reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16 + 4 * g) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] += acc[i][r]; s2[r] += acc[i][r] * acc[i][r]; }
+      }
+    }
+    if (kt + 1 < ntile) stash((kt + 1) & 1);
+    __syncthreads();
   }
   if (stat_partials != nullptr) {
 #pragma unroll
@@ -754,7 +787,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __
     __syncthreads();
     if (tid < 32) {
       const int which = tid >> 4, c = tid & 15;
-      stat_partials[tile.lin * 32 + tid] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      stat_partials[sup * 32 + tid] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     }
   }
 }
@@ -1005,6 +1038,12 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float
   if (owner) dw[i] = beta ? dw[i] + s : s;
 }
 
+// rows of `stat_partials` ([rows][2][16] floats) maavss_conv3d_c1_fwd writes: one per workgroup
+extern "C" int64_t maavss_conv3d_c1_fwd_nparts(int B, int T, int H, int W, int precise) {
+  const int64_t tiles = (int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T;
+  return precise == MODE_F16 ? cdiv(tiles, C1_TPW) : tiles;
+}
+
 extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_ws, float* y, float* stat_partials, int B,
                                     int T, int H, int W, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && w && w16_ws && y, "conv3d_c1_fwd: null pointer");
@@ -1012,7 +1051,7 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
   MAAVSS_CHECK_ARG(precise == MODE_F32 || precise == MODE_F16, "conv3d_c1_fwd: mode must be 1 (exact f32 VALU) or 2 (IEEE-half MFMA)");
   hipStream_t st = (hipStream_t)stream;
   if (precise == MODE_F16) {
-    hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel, dim3(xcd_grid((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T)), dim3(256), 0, st, x, w, y,
+    hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0, st, x, w, y,
                        stat_partials, B * T, T, H, W);
     MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_mfma_kernel");
     return MAAVSS_OK;

@@ -122,7 +122,7 @@ def conv3d_c1_fwd(x, w, want_stats=False, precise=MODE_F32):
     w16 = torch.empty(1200, device=x.device, dtype=torch.float32)
     part = None
     if want_stats:
-        part = torch.empty(((wd + 15) // 16) * ((h + 15) // 16) * b * t, 2, 16, device=x.device, dtype=torch.float32)
+        part = torch.empty(query("maavss_conv3d_c1_fwd_nparts", b, t, h, wd, int(precise)), 2, 16, device=x.device, dtype=torch.float32)
     call("maavss_conv3d_c1_fwd", ptr(x), ptr(w), ptr(w16), ptr(y), ptr(part), b, t, h, wd, int(precise), stream_ptr())
     return y, part
 
