@@ -16,7 +16,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 # The 16-bit path rounds conv operands (forward: IEEE half, backward: bf16).  What that does to the GRADIENTS was measured on the
-# CPU oracle one rounding at a time (scripts/grad_rounding_ablation.py -> profiles/r3_grad_rounding_ablation.txt):
+# CPU oracle one rounding at a time (tests/tools/grad_rounding_ablation.py -> profiles/r3_grad_rounding_ablation.txt):
 #   * the bf16 backward operands move the gradient tensors by 0.3-0.6 % relative L2 (1 % on one BatchNorm bias at the benched shape);
 #   * the IEEE-half FORWARD operands move them by 7-8 % on the first conv layers (8-11 % on visual_encoder.1.bias; the HIP path
 #     logged 8-17 % in round 2), bf16 forward operands by 28 %, a 16-bit mantissa by 1 %: error ~ sqrt(perturbation).  The encoder
@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 #     (the exact-f32 HIP path, 3e-6 forward distance, already sits 2-3e-3 from the oracle), not of a kernel, and splitting dy
 #     into bf16 hi + lo in the first layers' weight gradients changes nothing: 7.22 % -> 7.23 %.
 # Two computations that round at the same points also decorrelate layer by layer (a value next to a rounding boundary flips;
-# scripts/fwd_stage_diff.py: 2e-7 after conv0, 3e-4 after conv4), so the emulating twin is matched within a fraction of that
+# tests/tools/fwd_stage_diff.py: 2e-7 after conv0, 3e-4 after conv4), so the emulating twin is matched within a fraction of that
 # envelope, not element-exactly.  The gates below therefore are: (1) an ABSOLUTE cap on every gradient tensor against the fp32
 # oracle at ~2x the measured forward-rounding floor, plus direction (cosine); (2) not farther from the emulating
 # twin than that twin is from fp32; (3) the forward outputs, absolutely (mask-MSE 1e-5, loss).  What training sees over several

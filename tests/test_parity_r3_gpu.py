@@ -9,7 +9,7 @@
 Why the trajectory and not a tight per-tensor gradient bound is the gate for the 16-bit path: on these seeded-random inputs the
 encoder gradients are sums of ~1e6 cancelling contributions routed by MaxPool argmax / LeakyReLU sign; ANY forward perturbation
 eps re-routes a fraction ~eps of them, so the relative L2 distance of a gradient tensor scales as sqrt(eps) -- measured on the
-CPU oracle (scripts/grad_rounding_ablation.py -> profiles/r3_grad_rounding_ablation.txt): IEEE-half forward operands (11 bits)
+CPU oracle (tests/tools/grad_rounding_ablation.py -> profiles/r3_grad_rounding_ablation.txt): IEEE-half forward operands (11 bits)
 7 %, 16 mantissa bits 1.1 %, and the bf16 backward operands the round-2 verdict suspected 0.4-0.5 % (dy as bf16 hi + lo in the
 first two weight gradients: 7.22 % -> 7.23 %, nothing).  What training sees is the trajectory below.
 """

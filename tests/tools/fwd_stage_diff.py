@@ -2,7 +2,7 @@
 carries the difference that is not operand rounding.  GPU box only; oracle = checker."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import maavss_amd
 from oracle import avse_ref_cpu as orc

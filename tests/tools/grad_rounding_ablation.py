@@ -1,7 +1,7 @@
 """Which rounding of the 16-bit conv path moves the gradients, and by how much (CPU, oracle twin).
 
-    python scripts/grad_rounding_ablation.py P        > profiles/r3_grad_rounding_ablation.txt
-    python scripts/grad_rounding_ablation.py benched >> profiles/r3_grad_rounding_ablation.txt
+    python tests/tools/grad_rounding_ablation.py P        > profiles/r3_grad_rounding_ablation.txt
+    python tests/tools/grad_rounding_ablation.py benched >> profiles/r3_grad_rounding_ablation.txt
 
 Every Conv3d of the oracle twin (oracle/avse_ref_cpu.py) is replaced by an autograd node whose operand roundings are
 switchable one by one: forward x / w per layer, input-gradient dy / w, weight-gradient x / dy (layer 0, layer 1, layers 2-4).
@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import avse_ref_cpu as orc  # noqa: E402
 
 bf = lambda t: t.to(torch.bfloat16).float()          # noqa: E731
