@@ -49,4 +49,4 @@ def test_non_224_position_embedding_is_kept_and_interpolated(tmp_path):
 def test_missing_file_keeps_seeded_init_and_resize_is_ignored(capsys):
     va = maavss_amd.VideoAttention(path_to_weights="/nonexistent/dino.pth", resize=(112, 112), device="cpu")
     assert va.model.loaded_from is None and va.resize == (112, 112)
-    assert "not found" in capsys.readouterr().out
+    assert "not found" in capsys.readouterr().err          # a notice, on stderr: bench.py's stdout is exactly one JSON line
