@@ -355,7 +355,7 @@ def main():
             stage_row("maavss_stft_fwd", bytes_=per * summ["maavss_stft_fwd"]["calls"])
             if "stft_fwd" in stages:
                 stages["stft_fwd"]["note"] = ("one launch per step over B*T_a frames: at B=32 that is ~4k waves = one wave round of the chip "
-                                              "(launch/latency-bound); the kernel reaches 1.2 TB/s at B=256 and 1.4 TB/s at B=8192 "
+                                              "(launch/latency-bound); the kernel reaches 1.7 TB/s at B=256 and 2.0 TB/s at B=8192 "
                                               "(profiles/r3_stft_bench.json): one wave per frame is bound by its FFT + Philox vector work, DESIGN.md 9")
         if "maavss_adam_step" in summ:     # p, g, m, v read + p, m, v written: 28 B per parameter
             stage_row("maavss_adam_step", bytes_=sum(28.0 * a[4] for a in summ["maavss_adam_step"]["args"]))

@@ -9,6 +9,13 @@
 #include "common.h"
 
 
+// Round 3: (1) the waves of a workgroup are independent, so the FFT stages are ordered by the wave's own LDS queue (LDS operations of
+// one wave complete in issue order) and a compiler-level wave barrier instead of ten workgroup barriers per frame; (2) a workgroup
+// builds its twiddle table once and walks a grid-stride list of frame PAIRS; (3) two real frames share one complex FFT (z = a + i b,
+// A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i): half the butterflies and LDS passes per frame; (4) one Philox
+// block serves two bins (its four normals: re / im of bins f and f + 64) instead of one.  profiles/r3_stft_bench.json.
+#define STFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <int NFFT, int STFT_FPB>
 __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
     const float* __restrict__ audio, int64_t audio_stride, int length, const float* __restrict__ window, int hop,
@@ -23,64 +30,89 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
     sincospif(-2.0f * (float)q / (float)NFFT, &s, &c);
     tw[q] = make_float2(c, s);
   }
-  const int fid = blockIdx.x * STFT_FPB + wv;
-  const bool active = fid < total_frames;
-  const int b = active ? fid / n_frames : 0, t = active ? fid % n_frames : 0;
-  const float* a = audio + (int64_t)b * audio_stride;
-  for (int n = lane; n < NFFT; n += 64) {
-    int j = t * hop + n - NFFT / 2;
-    if (j < 0) j = -j;
-    if (j >= length) j = 2 * (length - 1) - j;
-    float v = active ? a[j] * window[n] : 0.f;
-    buf[0][wv][n] = make_float2(v, 0.f);
-  }
   __syncthreads();
-  int cur = 0;
-#pragma unroll
-  for (int s = 0; s < LOG2N; ++s) {
-    const int p = 1 << s;
-    for (int i = lane; i < NFFT / 2; i += 64) {
-      const int k = i & (p - 1);
-      float2 u0 = buf[cur][wv][i];
-      float2 u1 = buf[cur][wv][i + NFFT / 2];
-      float2 w = tw[k * (NFFT / (2 * p))];
-      float2 v = make_float2(u1.x * w.x - u1.y * w.y, u1.x * w.y + u1.y * w.x);
-      const int j = ((i - k) << 1) + k;
-      buf[cur ^ 1][wv][j] = make_float2(u0.x + v.x, u0.y + v.y);
-      buf[cur ^ 1][wv][j + p] = make_float2(u0.x - v.x, u0.y - v.y);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  if (!active) return;
   const int64_t plane = (int64_t)n_frames * n_bins_out;
-  float* yre = y + ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out;
-  float* yim = yre + plane;
-  float amax = 0.f;
-  for (int f = lane; f < n_bins_out; f += 64) {
-    float2 v = buf[cur][wv][f];
-    yre[f] = v.x;
-    yim[f] = v.y;
-    amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
-    if (x != nullptr) {
-      const int64_t ore = ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out + f;
-      float nr, ni;
-      if (noise != nullptr) {
-        nr = noise[ore];
-        ni = noise[ore + plane];
-      } else {
-        float g[4];
-        philox_normal4(seed, (uint64_t)fid * n_bins_out + f, g);
-        nr = g[0];
-        ni = g[1];
-      }
-      x[ore] = v.x + sigma * nr;
-      x[ore + plane] = v.y + sigma * ni;
+  const int npairs = (total_frames + 1) / 2;
+  for (int pid = blockIdx.x * STFT_FPB + wv; pid < npairs; pid += gridDim.x * STFT_FPB) {
+    const int fid0 = 2 * pid, fid1 = fid0 + 1;
+    const bool two_frames = fid1 < total_frames;
+    const int b0 = fid0 / n_frames, t0 = fid0 % n_frames;
+    const int b1 = two_frames ? fid1 / n_frames : b0, t1 = two_frames ? fid1 % n_frames : t0;
+    const float* a0 = audio + (int64_t)b0 * audio_stride;
+    const float* a1 = audio + (int64_t)b1 * audio_stride;
+    for (int n = lane; n < NFFT; n += 64) {
+      int j0 = t0 * hop + n - NFFT / 2, j1 = t1 * hop + n - NFFT / 2;
+      if (j0 < 0) j0 = -j0;
+      if (j0 >= length) j0 = 2 * (length - 1) - j0;
+      if (j1 < 0) j1 = -j1;
+      if (j1 >= length) j1 = 2 * (length - 1) - j1;
+      const float wn = window[n];
+      buf[0][wv][n] = make_float2(a0[j0] * wn, two_frames ? a1[j1] * wn : 0.f);
     }
-  }
-  if (clip_absmax != nullptr) {
-    amax = wave_max(amax);
-    if (lane == 0) atomicMax((unsigned int*)(clip_absmax + b), __float_as_uint(amax));  // amax >= 0
+    STFT_WAVE_SYNC();
+    int cur = 0;
+#pragma unroll
+    for (int s = 0; s < LOG2N; ++s) {
+      const int p = 1 << s;
+      for (int i = lane; i < NFFT / 2; i += 64) {
+        const int k = i & (p - 1);
+        float2 u0 = buf[cur][wv][i];
+        float2 u1 = buf[cur][wv][i + NFFT / 2];
+        float2 w = tw[k * (NFFT / (2 * p))];
+        float2 v = make_float2(u1.x * w.x - u1.y * w.y, u1.x * w.y + u1.y * w.x);
+        const int j = ((i - k) << 1) + k;
+        buf[cur ^ 1][wv][j] = make_float2(u0.x + v.x, u0.y + v.y);
+        buf[cur ^ 1][wv][j + p] = make_float2(u0.x - v.x, u0.y - v.y);
+      }
+      STFT_WAVE_SYNC();
+      cur ^= 1;
+    }
+    // ---- separate the two spectra and write them (+ the noisy copies); `fr` = 0 / 1 selects the frame of the pair
+#pragma unroll
+    for (int fr = 0; fr < 2; ++fr) {
+      if (fr == 1 && !two_frames) break;
+      const int fid = fr ? fid1 : fid0, b = fr ? b1 : b0, t = fr ? t1 : t0;
+      float* yre = y + ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out;
+      float* yim = yre + plane;
+      float amax = 0.f;
+      auto bin = [&](int f) __attribute__((always_inline)) {
+        const float2 z = buf[cur][wv][f], zn = buf[cur][wv][(NFFT - f) & (NFFT - 1)];
+        return fr == 0 ? make_float2(0.5f * (z.x + zn.x), 0.5f * (z.y - zn.y)) : make_float2(0.5f * (z.y + zn.y), -0.5f * (z.x - zn.x));
+      };
+      // bins in pairs (f, f + 64): one Philox block = four normals = the noise of both
+      for (int f0 = lane, jp = 0; f0 < n_bins_out; f0 += 128, ++jp) {
+        const int f1 = f0 + 64;
+        const bool two = f1 < n_bins_out;
+        const float2 v0 = bin(f0), v1 = two ? bin(f1) : make_float2(0.f, 0.f);
+        yre[f0] = v0.x;
+        yim[f0] = v0.y;
+        if (two) { yre[f1] = v1.x; yim[f1] = v1.y; }
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v1.x), fabsf(v1.y))));
+        if (x != nullptr) {
+          const int64_t o0 = ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out + f0;
+          float g[4];
+          if (noise != nullptr) {
+            g[0] = noise[o0];
+            g[1] = noise[o0 + plane];
+            g[2] = two ? noise[o0 + 64] : 0.f;
+            g[3] = two ? noise[o0 + 64 + plane] : 0.f;
+          } else {
+            philox_normal4(seed, ((uint64_t)fid * 8 + jp) * 64 + lane, g);
+          }
+          x[o0] = v0.x + sigma * g[0];
+          x[o0 + plane] = v0.y + sigma * g[1];
+          if (two) {
+            x[o0 + 64] = v1.x + sigma * g[2];
+            x[o0 + 64 + plane] = v1.y + sigma * g[3];
+          }
+        }
+      }
+      if (clip_absmax != nullptr) {
+        amax = wave_max(amax);
+        if (lane == 0) atomicMax((unsigned int*)(clip_absmax + b), __float_as_uint(amax));  // amax >= 0
+      }
+    }
+    STFT_WAVE_SYNC();      // the next pair overwrites buf[0][wv]
   }
 }
 
@@ -123,8 +155,9 @@ extern "C" int maavss_stft_fwd(const float* audio, int64_t batch, int64_t length
   MAAVSS_CHECK_ARG((int64_t)(n_frames - 1) * hop + n_fft / 2 - 1 < 2 * length - 1, "stft: frames run past the reflected signal");
   const int total = (int)(batch * n_frames);
   hipStream_t st = (hipStream_t)stream;
+  // grid-stride over the frames: at most 8 workgroups per CU worth of blocks (the twiddle table is built once per workgroup)
 #define LAUNCH(N, FPB)                                                                                         \
-  hipLaunchKernelGGL((stft_kernel<N, FPB>), dim3(cdiv(total, FPB)), dim3(64 * FPB), 0, st, audio, audio_stride, \
+  hipLaunchKernelGGL((stft_kernel<N, FPB>), dim3(cdiv(cdiv(total, 2), FPB) < 2048 ? cdiv(cdiv(total, 2), FPB) : 2048), dim3(64 * FPB), 0, st, audio, audio_stride, \
                      (int)length, window, hop, n_frames, n_bins_out, total, y, x, noise, sigma, seed, clip_absmax)
   if (n_fft == 256) LAUNCH(256, 4);
   else if (n_fft == 512) LAUNCH(512, 4);
