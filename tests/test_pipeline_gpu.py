@@ -1,0 +1,66 @@
+"""ClipPipeline (maavss_amd/pipeline.py): attention-frame extraction + STFT of batch i+1 on a side HIP stream under the training
+step of batch i -- the reference's data path (av_dataset.py:321,335-342) has no dependency on the optimizer step
+(train_avse_frames.py:150-181).  The pipelined loop must produce what the serial loop produces: the extractor's outputs bit for bit
+(same kernels, another stream), the training losses and weights up to the summation order of the split-K Linear kernels (f32
+atomics), over more batches than the pipeline has slots -- a missing event or a slot reused too early shows up as a mismatch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, T, W, FFT, HPF, NBATCH = 2, 8, 128, 256, 8, 5
+
+
+def _setup(seed):
+    import maavss_amd
+    from oracle import avse_ref_cpu as orc, stft_ref_cpu as sref, vit_ref_cpu as vref
+    hop, length, t_a = maavss_amd.calc_hop_size(T, HPF, 30, 16000)
+    n_bins = FFT // 2 + 1
+    shapes = ([B, 2, t_a, n_bins], [B, 1, T, W, W], HPF)
+    model = maavss_amd.AV_Fusion_Model_Frames(*shapes)
+    model.load_state_dict(orc.seeded_state_dict(orc.AVFusionFramesRef(*shapes), seed), strict=True)
+    model = model.cuda().train()
+    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth")
+    va.load_state_dict(vref.seeded_vit_state(3))
+    stft = maavss_amd.STFT(FFT, hop, noise_std=0.1, device="cuda")
+    step = maavss_amd.TrainStep(model, lr=1e-4)
+    frames = [vref.synthetic_frames(B * T, W, 100 + i).cuda() for i in range(NBATCH)]
+    audio = [sref.synthetic_audio(B, length, 200 + i).cuda() for i in range(NBATCH)]
+    return maavss_amd, model, va, stft, step, frames, audio
+
+
+def _train(step, x_v, x_stft, y_stft):
+    mid = T // 2
+    return step(x_stft, x_v, y_stft[:, :, mid * HPF:(mid + 1) * HPF, :], x_v[:, :, mid])[2].item()
+
+
+def test_pipelined_loop_equals_the_serial_loop():
+    maavss_amd, model, va, stft, step, frames, audio = _setup(61)
+    serial_losses, serial_attn = [], []
+    for i in range(NBATCH):
+        attn = va.attention_frames(frames[i], clip_frames=T).view(B, 1, T, W, W)
+        x_stft, y_stft = stft(audio[i], seed=i)
+        serial_attn.append(attn.clone())
+        serial_losses.append(_train(step, attn, x_stft, y_stft))
+    torch.cuda.synchronize()
+    w_serial = step.flat.params.clone()
+
+    maavss_amd, model, va, stft, step, frames, audio = _setup(61)
+    pipe = maavss_amd.ClipPipeline(va, stft, T)
+    pipe.submit(frames[0], audio[0], seed=0)
+    piped_losses = []
+    for i in range(NBATCH):
+        if i + 1 < NBATCH:
+            pipe.submit(frames[i + 1], audio[i + 1], seed=i + 1)
+        x_v, x_stft, y_stft = pipe.get()
+        assert torch.equal(x_v, serial_attn[i]), f"batch {i}: attention frames differ from the serial loop"
+        piped_losses.append(_train(step, x_v, x_stft, y_stft))
+        pipe.release()
+    pipe.drain()
+    for a, b in zip(serial_losses, piped_losses):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (serial_losses, piped_losses)
+    drift = (step.flat.params - w_serial).norm().item() / w_serial.norm().item()
+    print(f"[pipeline] {NBATCH} batches: losses {piped_losses[0]:.6f} .. {piped_losses[-1]:.6f}, weights vs serial loop rel L2 {drift:.2e}")
+    assert drift <= 1e-5
+    with pytest.raises(AssertionError):
+        pipe.get()                                   # nothing submitted
