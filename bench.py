@@ -49,6 +49,7 @@ def parse():
                     help="fp8: Q K^T / P V of the ViT blocks on fp8 (e4m3) MFMA (BASELINE config 'fp8 MFMA attention'); the headline line uses 'same'")
     ap.add_argument("--grad-wire", choices=["f32", "bf16"], default="f32",
                     help="wire format of the gradient all-reduce at N > 1 (bf16: half the xGMI bytes, bf16 sum over the ranks)")
+    ap.add_argument("--deterministic", action="store_true", help="no f32-atomic accumulation in the Linear kernels (bit-identical runs)")
     ap.add_argument("--pipeline", choices=["on", "off"], default="on",
                     help="on: attention-frame extraction + STFT of batch i+1 on a second HIP stream under the training step of batch i "
                          "(maavss_amd.ClipPipeline; the reference's data path has no dependency on the optimizer step); off: one stream")
@@ -164,6 +165,8 @@ def main():
 
     import maavss_amd
     from maavss_amd import _lib
+    if args.deterministic:
+        maavss_amd.set_deterministic(True)
     b, t, w, hpf = args.batch, args.frames, args.framesize, args.hops_per_frame
     hop, length, t_a = maavss_amd.calc_hop_size(t, hpf, 30, 16000)
     n_bins = args.fft_len // 2 + 1
@@ -414,7 +417,7 @@ def main():
                        "global_batch": b * world, "frames": t, "framesize": w, "fft_len": args.fft_len,
                        "parallelism": f"dp{world}", "streams": "2 (extraction of batch i+1 under the training step of batch i)" if pipe is not None else "1", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
                        "vit": args.vit_dtype, "vit_attention": "block-scaled fp8 (MX e4m3, e8m0 scale per 32; f32 accumulate -- wider than the config's bf16)" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
-                       "linear_lstm": "f32", "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank", "grad_all_reduce": f"{args.grad_wire} wire, per-module buckets in backward order",
+                       "linear_lstm": "f32" + (" (deterministic: no atomic split-K)" if args.deterministic else " (split-K by f32 atomics)"), "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank", "grad_all_reduce": f"{args.grad_wire} wire, per-module buckets in backward order",
                        "loss": loss_val},
             "roofline": roofline,
             "stages": stages,

@@ -57,6 +57,17 @@ int maavss_istft(const float* spec, int64_t batch, int n_frames, int n_bins_in, 
  * gradients autograd derives from them.  transA=0: A[m*lda+k], 1: A[k*lda+m]; transB=0: B[n*ldb+k]
  * (torch Linear weight layout), 1: B[k*ldb+n]; transC=0: C[m*ldc+n], 1: C[n*ldc+m].
  * act: 0 none, 1 tanh, 2 sigmoid.  split_k: 0 = auto, n>1 = split K over n blocks (f32 atomics). */
+/* Process-wide switch (default 0).  1: maavss_gemm_f32 takes no path that accumulates with f32 atomics (the split-K forms of the
+ * M = batch Linear layers and the automatic split-K of the generic kernel) -- bit-identical results run to run, at the price of
+ * slower weight streaming on those shapes.  Everything else in the library is deterministic already (conv weight gradients:
+ * partial + reduce).  No reference counterpart (torch on one device is deterministic for these layers). */
+int maavss_set_deterministic(int on);   /* returns the previous setting */
+int maavss_get_deterministic(void);
+/* Optional device scratch (16-byte aligned; the library never allocates) that lets deterministic mode keep the K split of the
+ * M = batch Linear forms: slices write partial sums [slices][32][cols], a second kernel adds them in slice order.  8.4 MB covers the
+ * reference shapes (fc1 8192 -> 4096 at 512-wide slices); shapes that need more fall back to one slice per output element.  One
+ * scratch per process: do not run Linear kernels of different streams concurrently in this mode.  NULL removes it. */
+int maavss_set_deterministic_workspace(float* ws, int64_t bytes);
 int maavss_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                     int64_t ldc, int transC, int64_t M, int64_t N, int64_t K, float alpha, int beta, int act,
                     int split_k, int precise, void* stream);

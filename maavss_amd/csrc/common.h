@@ -9,6 +9,8 @@
 #define MAAVSS_ERR_LAUNCH 2
 
 void maavss_set_error(const char* fmt, ...);
+int maavss_deterministic_flag(void);
+float* maavss_deterministic_ws(int64_t* floats);   // scratch for deterministic split-K partials (null if none was provided)   // api_core.hip: 1 = no atomic accumulation anywhere (maavss_set_deterministic)
 
 #define MAAVSS_CHECK_ARG(cond, ...)            \
   do {                                         \

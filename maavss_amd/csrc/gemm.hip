@@ -214,9 +214,9 @@ extern "C" int maavss_gemm_f32(const float* A, int64_t lda, int transA, const fl
   else cfg = 1;
   const int bm = cfg == 1 ? 64 : 128, bn = cfg == 0 ? 32 : (cfg == 1 ? 64 : 128);
   const int64_t blocks = (int64_t)cdiv(g.M, bm) * cdiv(g.N, bn);
-  if (split_k <= 0) {  // auto: fill the chip when the output grid alone cannot
+  if (split_k <= 0) {  // auto: fill the chip when the output grid alone cannot (never in deterministic mode: split-K sums with atomics)
     split_k = 1;
-    if (blocks < 512 && g.K >= 512) {
+    if (blocks < 512 && g.K >= 512 && !maavss_deterministic_flag()) {
       split_k = (int)((1024 + blocks - 1) / blocks);
       const int maxs = g.K / 128;
       if (split_k > maxs) split_k = maxs;

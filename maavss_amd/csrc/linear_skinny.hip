@@ -23,7 +23,8 @@ struct LinArgs {
   int64_t ld_act, ld_w, ld_out;
   int Mb, N, K;
   float alpha;
-  int beta, actfn, atomic;
+  int beta, actfn, atomic;   // atomic: 0 single slice, 1 split over slices with f32 atomics, 2 deterministic partials in `part`
+  float* part;               // atomic == 2: [slices][32][cols]
 };
 
 __device__ __forceinline__ float ls_act(float v, int a) {
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(512) void linear_fwd_skinny_kernel(LinArgs g) {
         if (m >= g.Mb) continue;
         float* c = g.out + (int64_t)m * g.ld_out + n;
         float v = a[r] * g.alpha;
-        if (g.atomic) {
+        if (g.atomic == 2) {                 // deterministic: this K slice's partial sum, added in slice order by linear_reduce_kernel
+          g.part[((int64_t)blockIdx.y * 32 + m) * g.N + n] = v;
+        } else if (g.atomic) {
           atomicAdd(c, v);
         } else {
           if (g.beta) v += *c;
@@ -148,7 +151,9 @@ __global__ __launch_bounds__(512) void linear_dx_skinny_kernel(LinArgs g) {
     if (m < g.Mb && k < g.K) {
       float* c = g.out + (int64_t)m * g.ld_out + k;
       v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
-      if (g.atomic) {
+      if (g.atomic == 2) {
+        *reinterpret_cast<float4*>(g.part + ((int64_t)blockIdx.y * 32 + m) * g.K + k) = v;
+      } else if (g.atomic) {
         atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w);
       } else {
         if (g.beta) { const float4 o = *reinterpret_cast<const float4*>(c); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -215,6 +220,17 @@ __global__ void linear_act_kernel(float* C, int64_t ldc, int rows, int cols, int
   }
 }
 
+// deterministic split: C[m][n] = act(sum over slices in order (+ C when beta))
+__global__ void linear_reduce_kernel(const float* __restrict__ part, int slices, float* C, int64_t ldc, int rows, int cols, int beta, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)rows * cols; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / cols), n = (int)(i % cols);
+    float* c = C + (int64_t)m * ldc + n;
+    float v = beta ? *c : 0.f;
+    for (int s = 0; s < slices; ++s) v += part[((int64_t)s * 32 + m) * cols + n];
+    *c = ls_act(v, act);
+  }
+}
+
 static int ls_blocks(int64_t elems) { const int b = cdiv(elems, 256); return b < 2048 ? b : 2048; }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -225,28 +241,37 @@ int maavss_linear_skinny_try(const float* A, int64_t lda, int transA, const floa
   *taken = 0;
   if (transC) return MAAVSS_OK;
   LinArgs g;
-  g.alpha = alpha; g.beta = beta; g.actfn = act; g.atomic = 0;
-  if (!transA && !transB && M <= 32 && N >= 512 && N % 4 == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+  g.alpha = alpha; g.beta = beta; g.actfn = act; g.atomic = 0; g.part = nullptr;
+  // deterministic mode: multi-slice cases are taken only when the caller provided scratch for the partial sums
+  const bool det = maavss_deterministic_flag() != 0;
+  int64_t ws_floats = 0;
+  float* det_ws = maavss_deterministic_ws(&ws_floats);
+  auto det_ok = [&](int64_t reduce_len, int slice_len, int64_t cols) { return !det || reduce_len <= slice_len || (det_ws && (int64_t)cdiv(reduce_len, slice_len) * 32 * cols <= ws_floats); };
+  if (!transA && !transB && det_ok(K, LS_KS, N) && M <= 32 && N >= 512 && N % 4 == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
       aligned16(A) && aligned16(B) && aligned16(C)) {
     // fwd: C[M][N] = A[M][K] . B[N][K]^T
     g.act = A; g.ld_act = lda; g.w = B; g.ld_w = ldb; g.out = C; g.ld_out = ldc; g.Mb = (int)M; g.N = (int)N; g.K = (int)K;
     const int slices = cdiv(K, LS_KS);
-    g.atomic = slices > 1;
-    if (g.atomic && !beta) hipLaunchKernelGGL(linear_zero_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N);
+    g.atomic = slices > 1 ? (det ? 2 : 1) : 0;
+    g.part = det_ws;
+    if (g.atomic == 1 && !beta) hipLaunchKernelGGL(linear_zero_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N);
     hipLaunchKernelGGL(linear_fwd_skinny_kernel, dim3(cdiv(N, 128), slices), dim3(512), 0, st, g);
-    if (g.atomic && act) hipLaunchKernelGGL(linear_act_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N, act);
+    if (g.atomic == 1 && act) hipLaunchKernelGGL(linear_act_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N, act);
+    if (g.atomic == 2) hipLaunchKernelGGL(linear_reduce_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, det_ws, slices, C, ldc, (int)M, (int)N, beta, act);
     MAAVSS_LAUNCH_CHECK("linear_fwd_skinny_kernel");
     *taken = 1;
     return MAAVSS_OK;
   }
-  if (!transA && transB && M <= 32 && N >= 256 && N % 4 == 0 && K >= LS_NS && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) {
+  if (!transA && transB && det_ok(K, LS_NS, N) && M <= 32 && N >= 256 && N % 4 == 0 && K >= LS_NS && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) {
     // dx: C[M][N] = A[M][K] . B[K][N]   (B = the weight [K rows][N columns]; K is the reduction)
     g.act = A; g.ld_act = lda; g.w = B; g.ld_w = ldb; g.out = C; g.ld_out = ldc; g.Mb = (int)M; g.N = (int)K; g.K = (int)N;
     const int slices = cdiv(K, LS_NS);
-    g.atomic = slices > 1;
-    if (g.atomic && !beta) hipLaunchKernelGGL(linear_zero_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N);
+    g.atomic = slices > 1 ? (det ? 2 : 1) : 0;
+    g.part = det_ws;
+    if (g.atomic == 1 && !beta) hipLaunchKernelGGL(linear_zero_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N);
     hipLaunchKernelGGL(linear_dx_skinny_kernel, dim3(cdiv(N, 64), slices), dim3(512), 0, st, g);
-    if (g.atomic && act) hipLaunchKernelGGL(linear_act_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N, act);
+    if (g.atomic == 1 && act) hipLaunchKernelGGL(linear_act_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, C, ldc, (int)M, (int)N, act);
+    if (g.atomic == 2) hipLaunchKernelGGL(linear_reduce_kernel, dim3(ls_blocks(M * N)), dim3(256), 0, st, det_ws, slices, C, ldc, (int)M, (int)N, beta, act);
     MAAVSS_LAUNCH_CHECK("linear_dx_skinny_kernel");
     *taken = 1;
     return MAAVSS_OK;

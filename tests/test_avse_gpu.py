@@ -341,3 +341,31 @@ def test_reference_constructor_guards():
     model = maavss_amd.AV_Fusion_Model_Frames([1, 2, 64, 257], [1, 1, 8, 256, 256], 8)
     with pytest.raises(maavss_amd._lib.MaavssError):
         model(torch.zeros(1, 2, 64, 257), torch.zeros(1, 1, 8, 256, 256))      # CPU tensors: no fallback
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """maavss_amd.set_deterministic(True): the split-K forms of the M = batch Linear layers accumulate with f32
+    atomics by default (reproducible to summation order); with the switch set, two runs of three optimizer steps from the same state
+    end bit-identical (the conv path, BatchNorm and Adam are deterministic already), and the result stays within summation-order
+    distance of the default mode's."""
+    import maavss_amd
+    m = dict(batch=2, frames=8, width=128, fft_len=256, hops_per_frame=8, seed=23)
+
+    def run():
+        model, _, (x_a, x_v, y_a, y_v) = _build(m, precise=False)
+        model.train()
+        step = maavss_amd.TrainStep(model, lr=1e-4)
+        losses = [step(x_a.cuda(), x_v.cuda(), y_a.cuda(), y_v.cuda())[2].item() for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, step.flat.params.clone()
+
+    prev = maavss_amd.set_deterministic(True)
+    try:
+        l1, p1 = run()
+        l2, p2 = run()
+    finally:
+        maavss_amd.set_deterministic(prev)
+    assert l1 == l2 and torch.equal(p1, p2)
+    l3, p3 = run()                                       # default (atomic split-K) mode
+    assert abs(l3[0] - l1[0]) <= 1e-6 * abs(l1[0]) + 1e-8
+    assert (p3 - p1).norm().item() <= 1e-4 * p1.norm().item()
