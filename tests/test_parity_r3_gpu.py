@@ -62,6 +62,14 @@ def test_ten_step_trajectory_of_the_16bit_path_follows_the_fp32_twin(lr, precise
     trajectories separate faster -- the exact-f32 HIP path runs as the control for how much of that is the 16-bit path."""
     import maavss_amd
     from oracle import avse_ref_cpu as orc
+    prev = maavss_amd.set_deterministic(True)       # reproducible figures: no atomic summation order in the Linear kernels
+    try:
+        _trajectory(maavss_amd, orc, lr, precise, loss_tol)
+    finally:
+        maavss_amd.set_deterministic(prev)
+
+
+def _trajectory(maavss_amd, orc, lr, precise, loss_tol):
     model, twin, (x_a, x_v, y_a, y_v) = _build(2, 8, 256, 512, 53, precise=precise, spatial_match="exact")
     w0 = {k: p.detach().clone() for k, p in twin.named_parameters()}
     opt = torch.optim.Adam(twin.parameters(), lr=lr)
