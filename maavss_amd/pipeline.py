@@ -30,6 +30,9 @@ class ClipPipeline:
         main = torch.cuda.current_stream()
         produced = torch.cuda.Event()
         produced.record(main)
+        # the caller may drop its references right after this call: tell the caching allocator that the side stream still reads them
+        frames.record_stream(self.side)
+        audio.record_stream(self.side)
         with torch.cuda.stream(self.side):
             self.side.wait_event(produced)
             if slot["consumed"] is not None:

@@ -74,3 +74,16 @@ def _pipelined_vs_serial():
     print(f"[pipeline] {NBATCH} batches: losses {piped_losses[0]:.6f} .. {piped_losses[-1]:.6f}; losses and weights bit-identical to the serial loop")
     with pytest.raises(AssertionError):
         pipe.get()                                   # nothing submitted
+    # inputs that the caller frees right after submit() (temporaries) must stay valid for the side stream: same values, fresh
+    # tensors, references dropped at once, allocator pressure in between
+    maavss_amd, model, va, stft, step, frames, audio = _setup(61)
+    pipe = maavss_amd.ClipPipeline(va, stft, T)
+    for i in range(3):
+        pipe.submit(frames[i].clone(), audio[i].clone(), seed=i)
+        junk = [torch.full_like(frames[i], float("nan")) for _ in range(2)]      # re-uses the freed blocks if they were released
+        del junk
+        if i >= 1:
+            x_v, x_stft, y_stft = pipe.get()
+            assert torch.equal(x_v, serial_attn[i - 1]) and torch.equal(y_stft, serial_stft[i - 1][1]), f"temporary inputs, batch {i - 1}"
+            pipe.release()
+    pipe.drain()
