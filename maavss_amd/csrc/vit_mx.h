@@ -46,6 +46,9 @@ static inline MxImages mx_images(void* ws, int64_t rows) {
   return m;
 }
 
+// Scale choice: the OCP MX recipe takes 2^(floor(log2 amax) - 8) and SATURATES block elements between 448 and 512 times the scale;
+// this one never saturates -- where the recipe would clip (amax / scale in (448, 512)) it takes the next power of two instead, at the
+// price of one bit of resolution for the rest of that block.  Any e8m0 scale is a valid MX encoding; the oracle emulates this one.
 // e8m0 scale (biased exponent byte) of a block with absolute maximum `amax`: the smallest power of two s with amax / s <= 448
 // (up to the rounding of amax * (1/448): a quotient of 448 (1 + 1e-7) still rounds to 448, e4m3 only overflows above 464).
 // amax = 0 -> byte 0 (2^-127): the block's values are exact zeros whatever the scale.  inv = 1 / s as a float (exact).
