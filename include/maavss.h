@@ -106,6 +106,25 @@ int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout,
                               int nchunk, int B, int T, int H, int W, int beta,
                               int precise /* 1: exact-f32 VALU; 0: bf16 operands on the MFMA (positions = K dimension) */, void* stream);
 
+/* The 16-bit first layer WITHOUT its conv output (avse_model_final.py:34-37: Conv3d(1,16,(3,5,5)) -> BatchNorm3d -> MaxPool3d((1,2,2))
+ * -> LeakyReLU): y [B][T][H][W][16] is the largest tensor of the step (1.6 GB at 32 x 16 x 224^2) and the layer is 59 GFLOP on
+ * an idle matrix pipe, so the convolution is run three times instead of stored once and read twice:
+ *   maavss_conv3d_c1_stats          conv (IEEE-half MFMA) -> stat_partials [maavss_conv3d_c1_fwd_nparts(.., 2)][2][16] only; `y` is
+ *                                   written ONLY if some |gamma[c]| < 1e-2 (the BatchNorm backward reduction then gathers from it);
+ *   maavss_conv3d_c1_bn_pool_act    conv again -> gamma (y - mean) invstd + beta -> 2x2 max pool -> LeakyReLU(0.01): out f32 and out16
+ *                                   (IEEE half, may be NULL) [B*T][H/2][W/2][16], argmax one byte per element (window position
+ *                                   dy * 2 + dx); bit-identical to maavss_conv3d_c1_fwd(.., 2) + maavss_bn_pool_act_fwd;
+ *   maavss_conv3d_c1_wgrad_bn_recompute   maavss_conv3d_c1_wgrad_bn(.., precise 0) with w [16][1][3][5][5] in place of y and the
+ *                                   BatchNorm bias bn_beta [16] in place of the pooled output: the tile's y is recomputed from the
+ *                                   staged halo and the LeakyReLU slope from its sign; bit-identical gradient. */
+int maavss_conv3d_c1_stats(const float* x, const float* w, const float* gamma, float* y, float* stat_partials, int B, int T, int H,
+                           int W, void* stream);
+int maavss_conv3d_c1_bn_pool_act(const float* x, const float* w, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, float* out, void* out16, void* argmax, int B, int T, int H, int W, void* stream);
+int maavss_conv3d_c1_wgrad_bn_recompute(const float* x, const float* w, const float* dout, const void* argmax, const float* mean,
+                                        const float* invstd, const float* bn_beta, const float* coef, int pool, float* dw, float* ws,
+                                        int nchunk, int B, int T, int H, int W, int beta, void* stream);
+
 /* ---- K9 BatchNorm (train mode) + MaxPool(1,p,p) + LeakyReLU / BatchNorm2d + Tanh -----------------
  * avse_model_final.py:35-37,...,55-57 (pool before activation) and :103-104 (pool = 1, act = 1).
  * y channels-last [B*T][H][W][C]; the pooled output (and its gradient) are addressed with element strides

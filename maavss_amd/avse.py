@@ -18,6 +18,8 @@ Differences from the reference constructor, all documented in DESIGN.md:
     need the exponent range); True = exact-f32 MFMA everywhere (parity path).  The Linear/LSTM layers are
     weight-streaming (HBM-bound) and always use exact-f32 MFMA.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -188,6 +190,8 @@ class AV_Fusion_Model_Frames(nn.Module):
         self.latent_channels = latent_channels
         self.output_stft_frames = hops_per_frame
         self.precise = bool(precise)
+        # 16-bit path: the first layer's conv output is recomputed instead of stored (MAAVSS_C1_RECOMPUTE=0: the storing kernels, for A/B)
+        self.c1_recompute = os.environ.get("MAAVSS_C1_RECOMPUTE", "1") != "0"
         self._bn_sync = None
         if self.frame_channels != 1:
             raise ValueError("the visual encoder takes single-channel attention frames (avse_model_final.py:34)")
@@ -487,7 +491,12 @@ class AV_Fusion_Model_Frames(nn.Module):
         for i in range(5):
             conv, bn = self._vis(i)
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
-            if i == 0:
+            # 16-bit first layer, training forward: the conv output (the step's largest tensor) is never stored -- pass 1 its
+            # BatchNorm sums, pass 2 conv again -> BatchNorm -> pool -> LeakyReLU, and the weight gradient recomputes it per tile
+            recompute = i == 0 and train and not self.precise and pool == 2 and self.c1_recompute
+            if recompute:
+                y, part = ops.conv3d_c1_stats(act_in, conv.weight.detach(), bn.weight.detach())
+            elif i == 0:
                 y, part = ops.conv3d_c1_fwd(act_in, conv.weight.detach(), want_stats=train, precise=pr)
             else:
                 wt = ops.conv3d_prep(conv.weight.detach(), 0, pr)
@@ -498,7 +507,10 @@ class AV_Fusion_Model_Frames(nn.Module):
             else:
                 mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
             act_in16 = None
-            if i < 4:
+            if recompute:
+                out, arg, act_in16 = ops.conv3d_c1_bn_pool_act(act_in, conv.weight.detach(), mean, invstd, bn.weight.detach(), bn.bias.detach())
+                strides = None
+            elif i < 4:
                 if self.precise:
                     out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
                 else:
@@ -509,7 +521,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 strides = (self.latent_channels * 2 * ts, self.s_v, 1, 2 * ts)
                 out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY,
                                                out=seq, strides=strides)
-            sv["vis"].append(dict(x=act_in, y=y, mean=mean, invstd=invstd, out=out, arg=arg, strides=strides))
+            sv["vis"].append(dict(x=act_in, y=y, mean=mean, invstd=invstd, out=out, arg=arg, strides=strides, recompute=recompute))
             act_in = out
         # --- STFT encoder (K10)
         cur, nchw = x_a, True
@@ -667,8 +679,12 @@ class AV_Fusion_Model_Frames(nn.Module):
                                            reduce_fn=bn_reduce)
                 if need.get(wname, False):
                     buf, beta = gbuf(wname)
-                    ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
-                                           dw=buf, beta=beta, precise=pr_conv)
+                    if s["recompute"]:
+                        ops.conv3d_c1_wgrad_bn_recompute(s["x"], conv.weight.detach(), dout.contiguous(), s["arg"], s["mean"],
+                                                         s["invstd"], bn.bias.detach(), coef, pool, dw=buf, beta=beta)
+                    else:
+                        ops.conv3d_c1_wgrad_bn(s["x"], s["y"], dout.contiguous(), out, s["arg"], s["mean"], s["invstd"], coef, pool,
+                                               dw=buf, beta=beta, precise=pr_conv)
                     out_grads[wname] = buf
                 continue
             # 16-bit path: dy is written as bf16 -- what both of its consumers (weight gradient, input gradient) round it to

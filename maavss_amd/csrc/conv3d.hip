@@ -662,122 +662,231 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
   }
 }
 
-// The same layer on the matrix pipe (16-bit path): implicit GEMM  y[pos][co] = sum_k A[pos][k] W[k][co]  with, per kd plane,
-// k = kh * 5 + kw (25 taps padded to one 32-deep MFMA step, zero weights in the pad).  One workgroup = a 16x16 output tile of one
-// (b, t) plane (as the f32 kernel); a wave owns 4 rows of 16 positions = 4 M-tiles.  The A fragment of lane (position l16,
-// k group g) is 8 taps of the IEEE-half halo image [3][20][24]: eight ds_read_u16 whose per-lane part (tap offset of
-// (g, j), position) sits in 8 address registers computed once and whose (kd, row) part is an immediate -- no address
-// arithmetic in the loop.  12 MFMAs per wave and tile instead of 300 packed FMAs per lane: the f32 VALU kernel ran at 62 of the
-// 157 TFLOP/s vector peak (0.99 ms per step); this one is bound by its 1.6 GB output.
-// Round 3: a workgroup walks C1_TPW consecutive tiles (tx fastest): the weight fragments and tap addresses are set up once,
-// the next tile's halo is requested before this tile's MFMAs and written to the other LDS buffer after them, and the BatchNorm
-// partial sums are reduced once per workgroup (one row of `stat_partials` per workgroup).  With one tile per workgroup (100 352
-// workgroups at 32 x 16 x 224^2) each lived ~14 us, most of it the prologue's dependent global loads.
+// The same layer on the matrix pipe (16-bit path): implicit GEMM  y[pos][co] = sum_k A[pos][k] W[k][co].  One workgroup = a 16x16
+// output tile of one (b, t) plane (as the f32 kernel); a wave owns 4 rows of 16 positions = 4 M-tiles.
+// K layout (round 3, second form): the 15 (kd, kh) tap rows are the 16-lane K groups, each 8 wide: kw = 0..4 + three zero-weight
+// slots, K = 128 = four 32-deep MFMA steps, group G = 4 m + g <-> (kd, kh) = (G / 5, G % 5), G = 15 all zero.  A lane's fragment is
+// then 8 CONSECUTIVE halo columns l16 .. l16 + 7 of one row: 16 bytes.  To make that one aligned LDS read the halo is kept as FOUR
+// copies shifted by 0..3 columns (copy s [kd][row][j] = halo[kd][row][j + s], 20 columns, 2400 B each -- a stride that puts the four
+// copies 32 B apart modulo the 128-B bank cycle): lane l16 = 4 q + s reads copy s at column 4 q, 8-byte aligned, as one ds_read2_b64.
+// 16 LDS reads + 16 MFMAs per wave and tile.  The first form (k = kh * 5 + kw over one 32-deep step per kd plane) built each fragment
+// from eight ds_read_u16 and four packs: 96 LDS instructions + 52 VALU per wave and tile, and with the per-tile 64-bit index
+// divisions on the CU's one scalar unit the statistics pass alone took 355 us; see DESIGN.md 9.
+// A workgroup walks C1_TPW consecutive tiles (tx fastest): weight fragments and addresses are set up once, the next tile's halo is
+// requested before this tile's MFMAs and written to the other LDS image after them, BatchNorm partial sums are reduced once per
+// workgroup (one row of `stat_partials` per workgroup).
+//
+// The conv output of this layer (1.6 GB at 32 x 16 x 224^2, the largest tensor of the step) does not have to exist.  The layer is
+// 59 GFLOP on a matrix pipe that is idle here and its input is 103 MB -- so the 16-bit path runs the convolution THREE times instead
+// of writing it once and reading it twice:
+//   EPI 1  (conv3d_c1_stats)        conv -> BatchNorm partial sums only (the store happens only when a channel's |gamma| is below
+//                                   BN_INV_MIN_GAMMA: the backward reduction then has to gather xhat from y, bn_pool.hip);
+//   EPI 2  (conv3d_c1_bn_pool_act)  conv again -> gamma (y - mean) invstd + beta -> 2x2 max pool -> LeakyReLU: the pooled
+//                                   activation (f32 + IEEE half) and the argmax byte, bit-identical to bn_pool_act_fwd_kernel on
+//                                   the stored y (same expressions, same scan order dy, dx, first maximum wins, NaN sticks);
+//   conv3d_c1_wgrad_recompute_kernel   conv a third time for xhat at every position of the BatchNorm backward.
+// EPI 0 is the storing form (eval-mode forward, tests).
 #define C1_TPW 8
+#define C1_MIN_GAMMA 1e-2f        // == BN_INV_MIN_GAMMA (bn_pool.hip): below it xhat is not recoverable from the pooled output
+#define C1H_COPY 1200             // halves per shifted copy [3][20][20]
+#define C1H_IMG (4 * C1H_COPY)    // halves per halo image (four copies): 9600 B (+ 16 B: the dump slot of C1Halo::stash)
+#define C1H_IMG_ALLOC (C1H_IMG + 8)
+
+// the five halo elements of a thread (element i = tid + 256 j of the [3][20][20] halo): tile-independent constants
+struct C1Halo {
+  int off[5];                     // offset inside the [bt][H][W] frame stack relative to (bt, y0, x0)
+  int lds[5];                     // half index inside copy 0 = (kd * 20 + row) * 20 + column
+  __device__ __forceinline__ void setup(int tid, int H, int W) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int i = tid + j * 256;
+      const int d = i / 400, rr = (i % 400) / 20, cc = i % 20;
+      off[j] = ((d - 1) * H + (rr - 2)) * W + (cc - 2);
+      lds[j] = i;
+    }
+  }
+  // values of the tile at (bt, t, y0, x0): zero outside the clip / the frame
+  __device__ __forceinline__ void fetch(const float* __restrict__ x, int tid, int bt, int t, int y0, int x0, int T, int H, int W, float v[5]) const {
+    const float* base = x + ((int64_t)bt * H + y0) * W + x0;
+    const bool inner = t >= 1 && t + 1 < T && y0 >= 2 && y0 + 18 <= H && x0 >= 2 && x0 + 18 <= W;      // uniform
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      v[j] = 0.f;
+      if (j < 4 || tid < 1200 - 1024) {
+        if (inner) {
+          v[j] = base[off[j]];
+        } else {
+          const int i = lds[j], d = i / 400, rr = (i % 400) / 20, cc = i % 20;
+          const int tt = t + d - 1, iy = y0 + rr - 2, ix = x0 + cc - 2;
+          if (tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = base[off[j]];
+        }
+      }
+    }
+  }
+  // write the 16-bit values into the four shifted copies of one image
+  __device__ __forceinline__ void stash(unsigned short* img, int tid, const unsigned short h[5]) const {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < 4 || tid < 1200 - 1024) {
+        const int cc = (tid + j * 256) % 20;
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)      // column cc of the halo is column cc - sft of copy sft; the first sft columns go to a dump slot (no branch)
+          img[cc >= sft ? sft * (C1H_COPY - 1) + lds[j] : C1H_IMG] = h[j];
+      }
+  }
+};
+
+// forward operands of a lane (co / position column l16 = 4 q + s, K group g, wave wv): weight fragments of the four K steps and the
+// byte offsets of its halo fragments (tile row 4 wv + i: add 40 i)
+struct C1Conv {
+  bf16x8 fw[4];
+  unsigned ra[4];
+  __device__ __forceinline__ void setup(const float* __restrict__ w, int l16, int g, int wv) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int G = 4 * m + g, Gc = G < 15 ? G : 14, kd = Gc / 5, kh = Gc % 5;
+      const float* wp = w + l16 * 75 + kd * 25 + kh * 5;
+      const bool live = G < 15;
+      const float w0 = live ? wp[0] : 0.f, w1 = live ? wp[1] : 0.f, w2 = live ? wp[2] : 0.f, w3 = live ? wp[3] : 0.f, w4 = live ? wp[4] : 0.f;
+      fw[m] = __builtin_bit_cast(bf16x8, make_uint4(pack2<MODE_F16>(w0, w1), pack2<MODE_F16>(w2, w3), pack2<MODE_F16>(w4, 0.f), 0u));
+      ra[m] = (unsigned)(((l16 & 3) * C1H_COPY + (kd * 20 + 4 * wv + kh) * 20 + (l16 & ~3)) * 2);
+    }
+  }
+  // acc[i][r] += y(channel 4 g + r, position (row 4 wv + i, column l16)) of the tile whose IEEE-half image is `img`
+  __device__ __forceinline__ void tile(const unsigned short* img, f32x4 acc[4]) const {
+    const char* hb = reinterpret_cast<const char*>(img);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(hb + ra[m] + i * 40), hi = *reinterpret_cast<const uint2*>(hb + ra[m] + i * 40 + 8);
+        Mma<MODE_F16>::mma(acc[i], fw[m], __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)));   // D[channel][position]
+      }
+  }
+};
+
+struct C1EpiArgs {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;             // EPI 1: decides the conditional store; EPI 2: the affine part
+  const float* beta;
+  float* out;                     // [BT][Hp][Wp][16] pooled activation
+  unsigned short* out16;          // the same as IEEE half (next conv's operand), may be null
+  unsigned char* argmax;          // [BT][Hp][Wp][16] window position dy * 2 + dx of the maximum
+  int Hp, Wp;
+};
+template <int EPI>
 __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  float* __restrict__ y, float* __restrict__ stat_partials,
-                                                                 int n_bt, int T, int H, int W) {
-  __shared__ __attribute__((aligned(16))) unsigned short halo[2][3][20][24];
+                                                                 int n_bt, int T, int H, int W, C1EpiArgs ep) {
+  __shared__ __attribute__((aligned(16))) unsigned short halo[2][C1H_IMG_ALLOC];
   __shared__ float red[4][2][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, g = lane >> 4;
-  const int nx = (W + 15) / 16, ny = (H + 15) / 16;
-  const int64_t total = (int64_t)nx * ny * n_bt, nsuper = (total + C1_TPW - 1) / C1_TPW;
-  const int64_t per = (nsuper + 7) / 8;
-  const int64_t sup = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD k walks the k-th eighth of the tile list
-  if ((int64_t)(blockIdx.x >> 3) >= per || sup >= nsuper) return;
-  const int64_t lin0 = sup * C1_TPW;
+  // tile list in 32-bit arithmetic (the entry points check nx * ny * n_bt < 2^31) and advanced one tile at a time: 64-bit
+  // divisions per tile run on the one scalar unit of a CU, shared by its 16 waves
+  const unsigned nx = (W + 15) / 16, ny = (H + 15) / 16;
+  const unsigned total = nx * ny * (unsigned)n_bt, nsuper = (total + C1_TPW - 1) / C1_TPW;
+  const unsigned per = (nsuper + 7) / 8;
+  const unsigned sup = (blockIdx.x & 7) * per + (blockIdx.x >> 3);             // XCD k walks the k-th eighth of the tile list
+  if ((blockIdx.x >> 3) >= per || sup >= nsuper) return;
+  const unsigned lin0 = sup * C1_TPW;
   const int ntile = (int)((total - lin0) < C1_TPW ? (total - lin0) : C1_TPW);
-  // weight fragments (B operand): lane (co = l16, g) holds W[co][kd][k = 8 g + j], j = 0..7, zero for k >= 25
-  bf16x8 fb[3];
-#pragma unroll
-  for (int kd = 0; kd < 3; ++kd) {
-    unsigned wq[4];
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-      const int k0 = 8 * g + 2 * jp;
-      const float a = k0 < 25 ? w[l16 * 75 + kd * 25 + k0] : 0.f, b = k0 + 1 < 25 ? w[l16 * 75 + kd * 25 + k0 + 1] : 0.f;
-      wq[jp] = pack2<MODE_F16>(a, b);
-    }
-    fb[kd] = __builtin_bit_cast(bf16x8, make_uint4(wq[0], wq[1], wq[2], wq[3]));
-  }
-  // per-lane byte addresses of the 8 taps of this lane's k group for position (row 4 wv, column l16) of kd plane 0
-  unsigned addr[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int k = 8 * g + j;
-    k = k < 25 ? k : 0;                    // padded k: any in-range halo element (its weight is zero, the halo is finite)
-    const int kh = k / 5, kw = k % 5;
-    addr[j] = (unsigned)(((4 * wv + kh) * 24 + l16 + kw) * 2);      // byte offset inside the halo image
-  }
-  // halo staging through registers: 1200 elements per tile, 5 per thread (the last round: 176 threads)
+  // columns 20 - s .. 19 of copy s are never written (no halo column behind them; zero-weight K slots read them): zero once
+  for (int i = tid; i < 2 * C1H_IMG_ALLOC / 8; i += 256) reinterpret_cast<uint4*>(&halo[0][0])[i] = make_uint4(0, 0, 0, 0);
+  C1Conv cv;
+  cv.setup(w, l16, g, wv);
+  C1Halo hl;
+  hl.setup(tid, H, W);
   float hreg[5];
-  auto fetch = [&](int64_t lin) __attribute__((always_inline)) {
-    const int tx = (int)(lin % nx), ty = (int)((lin / nx) % ny), bt = (int)(lin / ((int64_t)nx * ny)), t = bt % T;
-    const int x0 = tx * 16, y0 = ty * 16;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int i = tid + j * 256;
-      const int kd = i / 400, r = (i % 400) / 20, c = i % 20;
-      const int tt = t + kd - 1, iy = y0 + r - 2, ix = x0 + c - 2;
-      hreg[j] = 0.f;
-      if (i < 1200 && tt >= 0 && tt < T && iy >= 0 && iy < H && ix >= 0 && ix < W) hreg[j] = x[((int64_t)(bt + kd - 1) * H + iy) * W + ix];
-    }
+  unsigned ftx = lin0 % nx, fty = (lin0 / nx) % ny, fbt = lin0 / (nx * ny), ft = fbt % (unsigned)T;      // the tile being fetched
+  auto fetch = [&]() __attribute__((always_inline)) {
+    hl.fetch(x, tid, (int)fbt, (int)ft, (int)fty * 16, (int)ftx * 16, T, H, W, hreg);
+    if (++ftx == nx) { ftx = 0; if (++fty == ny) { fty = 0; ++fbt; if (++ft == (unsigned)T) ft = 0; } }
   };
   auto stash = [&](int buf) __attribute__((always_inline)) {
+    unsigned short h16[5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int i = tid + j * 256;
-      if (i < 1200) (&halo[buf][0][0][0])[i / 400 * 480 + (i % 400) / 20 * 24 + i % 20] = Mma<MODE_F16>::cvt(hreg[j]);
-    }
+    for (int j = 0; j < 5; ++j) h16[j] = Mma<MODE_F16>::cvt(hreg[j]);
+    hl.stash(&halo[buf][0], tid, h16);
   };
-  fetch(lin0);
+  fetch();
+  __syncthreads();                 // the zero fill is complete
   stash(0);
   __syncthreads();
+  unsigned ctx = lin0 % nx, cty = (lin0 / nx) % ny, cbt = lin0 / (nx * ny);    // the tile being computed
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  bool store = EPI == 0;
+  float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == 1) {
+    if (y != nullptr)
+      for (int c = 0; c < 16; ++c) store |= fabsf(ep.gamma[c]) < C1_MIN_GAMMA;      // uniform over the grid
+  }
+  if constexpr (EPI == 2) {
+    // the expressions of bn_pool_act_fwd_kernel, channels 4 g .. 4 g + 3
+    const float4 ga = *reinterpret_cast<const float4*>(ep.gamma + 4 * g), is = *reinterpret_cast<const float4*>(ep.invstd + 4 * g);
+    const float4 be = *reinterpret_cast<const float4*>(ep.beta + 4 * g), mu = *reinterpret_cast<const float4*>(ep.mean + 4 * g);
+    sc[0] = ga.x * is.x; sc[1] = ga.y * is.y; sc[2] = ga.z * is.z; sc[3] = ga.w * is.w;
+    sh[0] = be.x - mu.x * sc[0]; sh[1] = be.y - mu.y * sc[1]; sh[2] = be.z - mu.z * sc[2]; sh[3] = be.w - mu.w * sc[3];
+  }
   for (int kt = 0; kt < ntile; ++kt) {
-    const int64_t lin = lin0 + kt;
-    const int tx = (int)(lin % nx), ty = (int)((lin / nx) % ny), bt = (int)(lin / ((int64_t)nx * ny));
-    const int x0 = tx * 16, y0 = ty * 16;
-    if (kt + 1 < ntile) fetch(lin + 1);
+    const int bt = (int)cbt, x0 = (int)ctx * 16, y0 = (int)cty * 16;
+    if (++ctx == nx) { ctx = 0; if (++cty == ny) { cty = 0; ++cbt; } }
+    if (kt + 1 < ntile) fetch();
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* hbuf = reinterpret_cast<const char*>(&halo[kt & 1][0][0][0]);
-    // one M-tile (row i) x one kd plane: the (kd, row) displacement is an instruction immediate
-    auto step = [&](auto kd_c, auto i_c) __attribute__((always_inline)) {
-      constexpr int kd = decltype(kd_c)::value, i = decltype(i_c)::value;
-      constexpr int off = (kd * 20 + i) * 24 * 2;       // bytes: kd plane 20 x 24 halves, row 24 halves
-      // eight zero-extending 16-bit reads (per-lane part of the address in addr[], (kd, row) part a compile-time displacement),
-      // paired into the four fragment registers
-      const char* hb = hbuf + off;
-      const unsigned e0 = *reinterpret_cast<const unsigned short*>(hb + addr[0]), e1 = *reinterpret_cast<const unsigned short*>(hb + addr[1]);
-      const unsigned e2 = *reinterpret_cast<const unsigned short*>(hb + addr[2]), e3 = *reinterpret_cast<const unsigned short*>(hb + addr[3]);
-      const unsigned e4 = *reinterpret_cast<const unsigned short*>(hb + addr[4]), e5 = *reinterpret_cast<const unsigned short*>(hb + addr[5]);
-      const unsigned e6 = *reinterpret_cast<const unsigned short*>(hb + addr[6]), e7 = *reinterpret_cast<const unsigned short*>(hb + addr[7]);
-      const unsigned a0 = e0 | (e1 << 16), a1 = e2 | (e3 << 16), a2 = e4 | (e5 << 16), a3 = e6 | (e7 << 16);
-      const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
-      Mma<MODE_F16>::mma(acc[i], fb[kd], fa);     // D[channel][position]: a lane ends up with 4 consecutive channels of one position
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
-    step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
-    step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
-    // ---- lane holds channels 4 g + (0..3) of position (row 4 wv + i, column l16): 16-byte stores, the 16 lanes of a row group
-    // write 16 consecutive positions = 1 KiB contiguous per store instruction
+    cv.tile(&halo[kt & 1][0], acc);
+    // ---- lane holds channels 4 g + (0..3) of position (row 4 wv + i, column l16)
+    if constexpr (EPI != 2) {
+      // 16-byte stores, the 16 lanes of a row group write 16 consecutive positions = 1 KiB contiguous per store instruction
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int oy = y0 + 4 * wv + i, ox = x0 + l16;
-      if (oy < H && ox < W) {
-        *reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16 + 4 * g) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      for (int i = 0; i < 4; ++i) {
+        const int oy = y0 + 4 * wv + i, ox = x0 + l16;
+        if (oy < H && ox < W) {
+          if (store) *reinterpret_cast<float4*>(y + (((int64_t)bt * H + oy) * W + ox) * 16 + 4 * g) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] += acc[i][r]; s2[r] += acc[i][r] * acc[i][r]; }
+          for (int r = 0; r < 4; ++r) { s1[r] += acc[i][r]; s2[r] += acc[i][r] * acc[i][r]; }
+        }
+      }
+    } else {
+      // 2x2 windows: rows (4 wv + 0, 1) and (4 wv + 2, 3) live in this lane, columns (l16 even, odd) in a lane pair.  The even
+      // lane finishes the upper window, the odd lane the lower one: each sends the partner the two rows it does not finish.
+      const bool odd = (l16 & 1) != 0;
+      float own[2][4], rcv[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc[k][r] * sc[r] + sh[r], vb = acc[2 + k][r] * sc[r] + sh[r];
+          own[k][r] = odd ? vb : va;
+          rcv[k][r] = dpp_f32<0xB1, 0xf>(odd ? va : vb, 0.f);                       // quad_perm [1,0,3,2]: the pair partner's value
+        }
+      const int py = (y0 >> 1) + 2 * wv + (odd ? 1 : 0), px = (x0 >> 1) + (l16 >> 1);
+      if (py < ep.Hp && px < ep.Wp) {
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = (dx == 1) == odd ? own[dy][r] : rcv[dy][r];
+              if (v > best[r] || (v != v && best[r] == best[r])) { best[r] = v; bi[r] = dy * 2 + dx; }
+            }
+        float a4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a4[r] = best[r] > 0.f ? best[r] : 0.01f * best[r];
+        const int64_t pp = (((int64_t)bt * ep.Hp + py) * ep.Wp + px) * 16 + 4 * g;
+        *reinterpret_cast<float4*>(ep.out + pp) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        if (ep.out16 != nullptr) *reinterpret_cast<uint2*>(ep.out16 + pp) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
+        *reinterpret_cast<uchar4*>(ep.argmax + pp) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
       }
     }
     if (kt + 1 < ntile) stash((kt + 1) & 1);
     __syncthreads();
   }
-  if (stat_partials != nullptr) {
+  if (EPI != 2 && stat_partials != nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       s1[r] = row16_sum(s1[r]);
@@ -787,7 +896,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __
     __syncthreads();
     if (tid < 32) {
       const int which = tid >> 4, c = tid & 15;
-      stat_partials[sup * 32 + tid] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      stat_partials[(int64_t)sup * 32 + tid] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     }
   }
 }
@@ -812,6 +921,7 @@ struct C1BnArgs {
   const float* mean;
   const float* invstd;
   const float* coef;            // [3][16]: gamma*invstd, mean(dz), mean(dz*xhat)   (bn_bwd_finalize_kernel)
+  const float* beta;            // recompute kernel only: the sign of the pooled output is re-derived from the recomputed y
   int pool, Hp, Wp;
 };
 template <bool FUSE_BN>
@@ -1031,6 +1141,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// conv3d_c1_wgrad_recompute_kernel: the same product WITHOUT the stored conv output: the tile's y is recomputed from the halo that is
+// staged anyway (C1Conv on an IEEE-half image of it: the arithmetic of conv3d_c1_fwd_mfma_kernel, so xhat is bit-identical to what the
+// forward normalised).  The MFMA result layout -- lane (column l16, channel group g) holds channels 4 g .. 4 g + 3 of the positions
+// (row 4 wv + i, l16) -- is also the dy-formation mapping: each lane forms its 4 x 4 values from registers and writes them transposed.
+// The bf16 halo of the weight-gradient product is kept in the same four-shifted-copies form: the A fragment of lane (tap, k group) is 8
+// consecutive columns starting at kw + 8 (g & 1), i.e. copy kw & 3 at an 8-byte aligned column -- one ds_read2_b64 instead of eight
+// 16-bit reads and four packs.  Both images are double-buffered and the next tile's halo is fetched a tile ahead.
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_recompute_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                        float* __restrict__ partials, int T, int H, int W, int tiles_x,
+                                                                        int tiles_y, int BT, int tiles_per_chunk, int nchunk, C1BnArgs bn) {
+  constexpr int DYS = 256 + 8;
+  // [2 buffers][half image | bf16 image] + dyT; the final reduction (20480 B) reuses the front
+  __shared__ __attribute__((aligned(16))) unsigned short img[2][2][C1H_IMG_ALLOC];
+  __shared__ __attribute__((aligned(16))) unsigned short dyT[16 * DYS];
+  static_assert(sizeof(unsigned short) * 4 * C1H_IMG_ALLOC >= 4 * 80 * 16 * 4, "reduction scratch");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15, g = lane >> 4;
+  const int tiles_total = BT * tiles_x * tiles_y;
+  const int chunk = (blockIdx.x & 7) * ((nchunk + 7) / 8) + (blockIdx.x >> 3);
+  if (chunk >= nchunk) return;
+  for (int i = tid; i < 4 * C1H_IMG_ALLOC / 8; i += 256) reinterpret_cast<uint4*>(&img[0][0][0])[i] = make_uint4(0, 0, 0, 0);
+  // byte offsets of the A fragments of the 5 tap tiles (K step ks: add 80 ks)
+  unsigned abase[5];
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt) {
+    int tap = 16 * mt + l16;
+    tap = tap < 75 ? tap : 74;                                       // rows 75..79 of the last tile: computed, never stored
+    const int kd = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
+    abase[mt] = (unsigned)(((kw & 3) * C1H_COPY + (kd * 20 + kh + (g >> 1)) * 20 + (kw & ~3) + 8 * (g & 1)) * 2);
+  }
+  C1Conv cv;
+  cv.setup(w, l16, g, wv);
+  C1Halo hl;
+  hl.setup(tid, H, W);
+  // the per-channel constants of the dy formula live in LDS (24 registers otherwise, which cost the third wave per SIMD)
+  __shared__ __attribute__((aligned(16))) float cst[6][16];          // mean, invstd, gamma invstd, mean(dz), mean(dz xhat), beta - mean gamma invstd
+  if (tid < 16) {
+    const float m_ = bn.mean[tid], c0_ = bn.coef[tid];
+    cst[0][tid] = m_; cst[1][tid] = bn.invstd[tid]; cst[2][tid] = c0_; cst[3][tid] = bn.coef[16 + tid]; cst[4][tid] = bn.coef[32 + tid];
+    cst[5][tid] = bn.beta[tid] - m_ * c0_;
+  }
+  f32x4 acc[5];
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tile_beg = chunk * tiles_per_chunk, tile_end = min(tiles_total, tile_beg + tiles_per_chunk);
+  if (tile_beg >= tile_end) {                                        // an empty chunk still owns its row of partials
+    for (int i = tid; i < 1200; i += 256) partials[(int64_t)chunk * 1200 + i] = 0.f;
+    return;
+  }
+  int tx = tile_beg % tiles_x, ty = (tile_beg / tiles_x) % tiles_y, bt = tile_beg / (tiles_x * tiles_y), t = bt % T;
+  float hreg[5];
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+    unsigned short h16[5], b16[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { h16[j] = Mma<MODE_F16>::cvt(hreg[j]); b16[j] = f2bf(hreg[j]); }
+    hl.stash(&img[buf][0][0], tid, h16);
+    hl.stash(&img[buf][1][0], tid, b16);
+  };
+  hl.fetch(x, tid, bt, t, ty * 16, tx * 16, T, H, W, hreg);
+  __syncthreads();                                                   // zero fill complete
+  stash(0);
+  __syncthreads();
+  for (int tile = tile_beg, it = 0; tile < tile_end; ++tile, ++it) {
+    const int x0 = tx * 16, y0 = ty * 16, cbt = bt;
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++bt; if (++t == T) t = 0; } }
+    // the pooled operands of this lane's four positions and the next tile's halo: issued first, used after the conv
+    float4 dv[4];
+    uchar4 am[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = min(y0 + 4 * wv + i, H - 1), ox = min(x0 + l16, W - 1);
+      const int py = min(oy / bn.pool, bn.Hp - 1), px = min(ox / bn.pool, bn.Wp - 1);
+      const int64_t pp = (((int64_t)cbt * bn.Hp + py) * bn.Wp + px) * 16 + 4 * g;
+      am[i] = *reinterpret_cast<const uchar4*>(bn.argmax + pp);
+      dv[i] = *reinterpret_cast<const float4*>(bn.dout + pp);
+    }
+    if (tile + 1 < tile_end) hl.fetch(x, tid, bt, t, ty * 16, tx * 16, T, H, W, hreg);
+    // ---- y of the tile (forward arithmetic)
+    f32x4 z[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cv.tile(&img[it & 1][0][0], z);
+    // ---- dy of this lane's positions (the arithmetic of bn_pool_act_bwd_dx_kernel), transposed bf16 into LDS
+    const float4 mu = *reinterpret_cast<const float4*>(&cst[0][4 * g]), is = *reinterpret_cast<const float4*>(&cst[1][4 * g]);
+    const float4 k0 = *reinterpret_cast<const float4*>(&cst[2][4 * g]), k1 = *reinterpret_cast<const float4*>(&cst[3][4 * g]);
+    const float4 k2 = *reinterpret_cast<const float4*>(&cst[4][4 * g]), sh = *reinterpret_cast<const float4*>(&cst[5][4 * g]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = y0 + 4 * wv + i, ox = x0 + l16, pos = (4 * wv + i) * 16 + l16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < H && ox < W) {
+        const int py = oy / bn.pool, px = ox / bn.pool;
+        float gg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (py < bn.Hp && px < bn.Wp) {
+          const int here = (oy - py * bn.pool) * bn.pool + (ox - px * bn.pool);
+          // the pooled output is positive exactly when the forward's pre-activation at the argmax was: y * (gamma invstd) + (beta - mean gamma invstd),
+          // the expression of conv3d_c1_fwd_mfma_kernel<2> on the same recomputed y -- `out` is not read
+          if (am[i].x == here) gg[0] = dv[i].x * (z[i][0] * k0.x + sh.x > 0.f ? 1.f : 0.01f);
+          if (am[i].y == here) gg[1] = dv[i].y * (z[i][1] * k0.y + sh.y > 0.f ? 1.f : 0.01f);
+          if (am[i].z == here) gg[2] = dv[i].z * (z[i][2] * k0.z + sh.z > 0.f ? 1.f : 0.01f);
+          if (am[i].w == here) gg[3] = dv[i].w * (z[i][3] * k0.w + sh.w > 0.f ? 1.f : 0.01f);
+        }
+        v.x = k0.x * (gg[0] - k1.x - (z[i][0] - mu.x) * is.x * k2.x);
+        v.y = k0.y * (gg[1] - k1.y - (z[i][1] - mu.y) * is.y * k2.y);
+        v.z = k0.z * (gg[2] - k1.z - (z[i][2] - mu.z) * is.z * k2.z);
+        v.w = k0.w * (gg[3] - k1.w - (z[i][3] - mu.w) * is.w * k2.w);
+      }
+      dyT[(4 * g + 0) * DYS + pos] = f2bf(v.x);
+      dyT[(4 * g + 1) * DYS + pos] = f2bf(v.y);
+      dyT[(4 * g + 2) * DYS + pos] = f2bf(v.z);
+      dyT[(4 * g + 3) * DYS + pos] = f2bf(v.w);
+    }
+    __syncthreads();
+    const char* hb0 = reinterpret_cast<const char*>(&img[it & 1][1][0]);
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      const int ks = wv * 2 + ksl;                                   // positions 32 ks .. 32 ks + 31 = tile rows 2 ks, 2 ks + 1
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(dyT + l16 * DYS + 32 * ks + 8 * g);
+      const char* hb = hb0 + ks * 80;
+#pragma unroll
+      for (int mt = 0; mt < 5; ++mt) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(hb + abase[mt]), hi = *reinterpret_cast<const uint2*>(hb + abase[mt] + 8);
+        Mma<MODE_BF16>::mma(acc[mt], __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), fb);
+      }
+    }
+    if (tile + 1 < tile_end) stash((it + 1) & 1);
+    __syncthreads();
+  }
+  // ---- sum the four waves: lane (co = l16, g) holds taps 16 mt + 4 g + r
+  float* red = reinterpret_cast<float*>(&img[0][0][0]);              // [4 waves][80 taps][16 co]
+#pragma unroll
+  for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wv * 80 + 16 * mt + 4 * g + r) * 16 + l16] = acc[mt][r];
+  __syncthreads();
+  for (int i = tid; i < 1200; i += 256) {     // i = c * 75 + tap: [chunk][c][tap]
+    const int c = i / 75, tap = i % 75;
+    partials[(int64_t)chunk * 1200 + i] = red[tap * 16 + c] + red[(80 + tap) * 16 + c] + red[(160 + tap) * 16 + c] + red[(240 + tap) * 16 + c];
+  }
+}
+
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int nchunk, int beta) {
   bool owner;
   int i;
@@ -1048,11 +1298,12 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
                                     int T, int H, int W, int precise, void* stream) {
   MAAVSS_CHECK_ARG(x && w && w16_ws && y, "conv3d_c1_fwd: null pointer");
   MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "conv3d_c1_fwd: empty problem");
+  MAAVSS_CHECK_ARG((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31) && (int64_t)B * T * H * W < (1LL << 40), "conv3d_c1: too many tiles");
   MAAVSS_CHECK_ARG(precise == MODE_F32 || precise == MODE_F16, "conv3d_c1_fwd: mode must be 1 (exact f32 VALU) or 2 (IEEE-half MFMA)");
   hipStream_t st = (hipStream_t)stream;
   if (precise == MODE_F16) {
-    hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0, st, x, w, y,
-                       stat_partials, B * T, T, H, W);
+    hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel<0>, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0, st, x, w, y,
+                       stat_partials, B * T, T, H, W, C1EpiArgs{});
     MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_mfma_kernel");
     return MAAVSS_OK;
   }
@@ -1060,6 +1311,38 @@ extern "C" int maavss_conv3d_c1_fwd(const float* x, const float* w, float* w16_w
   hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(xcd_grid((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T)), dim3(256), 0, st, x, w16_ws, y,
                      stat_partials, B * T, T, H, W);
   MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_kernel");
+  return MAAVSS_OK;
+}
+
+// The 16-bit first layer without its conv output (see conv3d_c1_fwd_mfma_kernel): pass 1, BatchNorm partial sums.  `y` is written
+// only when some |gamma[c]| < 1e-2 (the backward reduction then gathers xhat from it); stat_partials as maavss_conv3d_c1_fwd(.., 2).
+extern "C" int maavss_conv3d_c1_stats(const float* x, const float* w, const float* gamma, float* y, float* stat_partials, int B, int T,
+                                      int H, int W, void* stream) {
+  MAAVSS_CHECK_ARG(x && w && gamma && y && stat_partials, "conv3d_c1_stats: null pointer");
+  MAAVSS_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0, "conv3d_c1_stats: empty problem");
+  MAAVSS_CHECK_ARG((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31) && (int64_t)B * T * H * W < (1LL << 40), "conv3d_c1: too many tiles");
+  C1EpiArgs ep = {};
+  ep.gamma = gamma;
+  hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel<1>, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0,
+                     (hipStream_t)stream, x, w, y, stat_partials, B * T, T, H, W, ep);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_mfma_kernel<1>");
+  return MAAVSS_OK;
+}
+
+// pass 2: conv again -> BatchNorm -> MaxPool(1,2,2) -> LeakyReLU(0.01).  out [B*T][H/2][W/2][16] f32, out16 the same as IEEE half
+// (may be null), argmax one byte per element.
+extern "C" int maavss_conv3d_c1_bn_pool_act(const float* x, const float* w, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, float* out, void* out16, void* argmax, int B, int T, int H, int W,
+                                            void* stream) {
+  MAAVSS_CHECK_ARG(x && w && mean && invstd && gamma && beta && out && argmax, "conv3d_c1_bn_pool_act: null pointer");
+  MAAVSS_CHECK_ARG(B > 0 && T > 0 && H >= 2 && W >= 2, "conv3d_c1_bn_pool_act: empty problem");
+  MAAVSS_CHECK_ARG((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31) && (int64_t)B * T * H * W < (1LL << 40), "conv3d_c1: too many tiles");
+  C1EpiArgs ep;
+  ep.mean = mean; ep.invstd = invstd; ep.gamma = gamma; ep.beta = beta; ep.out = out; ep.out16 = (unsigned short*)out16;
+  ep.argmax = (unsigned char*)argmax; ep.Hp = H / 2; ep.Wp = W / 2;
+  hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel<2>, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0,
+                     (hipStream_t)stream, x, w, nullptr, nullptr, B * T, T, H, W, ep);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_fwd_mfma_kernel<2>");
   return MAAVSS_OK;
 }
 
@@ -1090,6 +1373,26 @@ extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw
   return c1_wgrad_launch(x, dy, dw, ws, nchunk, B, T, H, W, beta, nullptr, (hipStream_t)stream);
 }
 
+// maavss_conv3d_c1_wgrad_bn on the 16-bit path without the stored conv output: `w` = the layer's weights [16][1][3][5][5], y is
+// recomputed per tile (conv3d_c1_wgrad_recompute_kernel).  bf16 backward operands, IEEE-half forward operands for the recompute.
+extern "C" int maavss_conv3d_c1_wgrad_bn_recompute(const float* x, const float* w, const float* dout, const void* argmax,
+                                                   const float* mean, const float* invstd, const float* bn_beta, const float* coef, int pool,
+                                                   float* dw, float* ws, int nchunk, int B, int T, int H, int W, int beta, void* stream) {
+  MAAVSS_CHECK_ARG(x && w && dout && argmax && mean && invstd && bn_beta && coef && dw && ws, "conv3d_c1_wgrad_bn_recompute: null pointer");
+  MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn_recompute: bad sizes (pool must be 2 or 3)");
+  C1BnArgs bn;
+  bn.dout = dout; bn.out = nullptr; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
+  bn.beta = bn_beta; bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
+  const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, 16);
+  const int tiles_total = B * T * tiles_x * tiles_y;
+  hipLaunchKernelGGL(conv3d_c1_wgrad_recompute_kernel, dim3(cdiv(nchunk, 8) * 8), dim3(256), 0, (hipStream_t)stream, x, w, ws, T, H, W,
+                     tiles_x, tiles_y, B * T, cdiv(tiles_total, nchunk), nchunk, bn);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_recompute_kernel");
+  hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(75), dim3(256), 0, (hipStream_t)stream, ws, dw, nchunk, beta);
+  MAAVSS_LAUNCH_CHECK("conv3d_c1_wgrad_reduce_kernel");
+  return MAAVSS_OK;
+}
+
 extern "C" int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout, const float* out, const void* argmax,
                                          const float* mean, const float* invstd, const float* coef, int pool, float* dw, float* ws,
                                          int nchunk, int B, int T, int H, int W, int beta, int precise, void* stream) {
@@ -1098,6 +1401,6 @@ extern "C" int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const f
   MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn: bad sizes (pool must be 2 or 3)");
   C1BnArgs bn;
   bn.dout = dout; bn.out = out; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
-  bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
+  bn.beta = nullptr; bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
   return c1_wgrad_launch(x, y, dw, ws, nchunk, B, T, H, W, beta, &bn, (hipStream_t)stream, precise == MODE_BF16);
 }

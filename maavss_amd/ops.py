@@ -156,6 +156,47 @@ def conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, pool, dw=None, 
     return dw
 
 
+def conv3d_c1_stats(x, w, gamma):
+    """16-bit first layer, pass 1: BatchNorm partial sums of the conv output, which is NOT stored (the returned y is
+    uninitialised memory unless some |gamma| < 1e-2: the degenerate case in which the BatchNorm backward gathers from it)."""
+    _f32(x, w, gamma)
+    b, t, h, wd = x.shape
+    y = torch.empty(b, t, h, wd, 16, device=x.device, dtype=torch.float32)
+    part = torch.empty(query("maavss_conv3d_c1_fwd_nparts", b, t, h, wd, MODE_F16), 2, 16, device=x.device, dtype=torch.float32)
+    call("maavss_conv3d_c1_stats", ptr(x), ptr(w), ptr(gamma), ptr(y), ptr(part), b, t, h, wd, stream_ptr())
+    return y, part
+
+
+def conv3d_c1_bn_pool_act(x, w, mean, invstd, gamma, beta, want16=True):
+    """pass 2: conv again -> BatchNorm -> MaxPool(1,2,2) -> LeakyReLU: (out f32, argmax u8, out16 IEEE half), [B,T,H//2,W//2,16]."""
+    _f32(x, w, mean, invstd, gamma, beta)
+    b, t, h, wd = x.shape
+    hp, wp = h // 2, wd // 2
+    out = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.float32)
+    arg = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.uint8)
+    out16 = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.float16) if want16 else None
+    call("maavss_conv3d_c1_bn_pool_act", ptr(x), ptr(w), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(out16), ptr(arg),
+         b, t, h, wd, stream_ptr())
+    return out, arg, out16
+
+
+def conv3d_c1_wgrad_bn_recompute(x, w, dout, arg, mean, invstd, bn_beta, coef, pool, dw=None, beta=0, nchunk=None):
+    """conv3d_c1_wgrad_bn (bf16 MFMA form) with the conv output recomputed per tile from x and the weights w (and the sign of the
+    pooled output from it and the BatchNorm bias bn_beta)."""
+    _f32(x, w, dout, mean, invstd, bn_beta, coef, dw)
+    b, t, h, wd = x.shape
+    assert dout.is_contiguous() and w.is_contiguous()
+    if nchunk is None:
+        cap = int(os.environ.get("MAAVSS_C1_NCHUNK", "1024"))
+        nchunk = max(1, min(cap, (b * t * ((h + 15) // 16) * ((wd + 15) // 16)) // 2))
+    ws = torch.empty(nchunk * 1200, device=x.device, dtype=torch.float32)
+    if dw is None:
+        dw, beta = torch.empty(16, 1, 3, 5, 5, device=x.device, dtype=torch.float32), 0
+    call("maavss_conv3d_c1_wgrad_bn_recompute", ptr(x), ptr(w), ptr(dout), ptr(arg), ptr(mean), ptr(invstd), ptr(bn_beta), ptr(coef), pool,
+         ptr(dw), ptr(ws), nchunk, b, t, h, wd, int(beta), stream_ptr())
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------- batch norm
 def bn_stats(y2d_rows, c):
     """y: any contiguous channels-last tensor with last dim c -> partial sums [nblk,2,c]."""

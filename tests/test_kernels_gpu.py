@@ -300,6 +300,40 @@ def test_conv3d_c1_wgrad_bn_mfma_matches_the_f32_kernel(b, t, h, w):
     close(dw_acc, (2 * dw16).cpu(), 1e-4, 1e-4 * dw16.abs().max().item())
 
 
+@pytest.mark.parametrize("b,t,h,w", [(2, 3, 40, 24), (1, 2, 33, 50), (1, 9, 64, 80), (2, 8, 224, 224)])
+def test_conv3d_c1_without_the_stored_conv_output_is_bit_identical(b, t, h, w):
+    """The 16-bit first layer's three recompute passes (statistics only; conv -> BatchNorm -> 2x2 pool -> LeakyReLU; weight gradient
+    with the tile's conv output recomputed) against the kernels that store y [B,T,H,W,16] and read it back: same partial sums, same
+    pooled activation / IEEE-half copy / argmax bytes, same weight gradient -- bit for bit (odd sizes: partial tiles and a dropped
+    last row / column of the pool; (1, 9, ...): a workgroup's tile walk ends inside a plane)."""
+    from maavss_amd import ops
+    x = torch.rand(b, t, h, w, generator=torch.Generator().manual_seed(11)).cuda()
+    wgt = rnd(16, 1, 3, 5, 5, seed=12, scale=0.1).cuda()
+    gamma, beta = (1 + 0.3 * rnd(16, seed=13)).cuda(), (0.2 * rnd(16, seed=14)).cuda()
+    y, part = ops.conv3d_c1_fwd(x, wgt, want_stats=True, precise=ops.MODE_F16)
+    y2, part2 = ops.conv3d_c1_stats(x, wgt, gamma)
+    assert torch.equal(part, part2)
+    mean, invstd = ops.bn_finalize(part, b * t * h * w)
+    out, arg, out16 = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, 2, ops.BN_LEAKY, want16=True)
+    o2, a2, o16 = ops.conv3d_c1_bn_pool_act(x, wgt, mean, invstd, gamma, beta)
+    assert torch.equal(out, o2) and torch.equal(arg, a2) and torch.equal(out16.view(torch.int16), o16.view(torch.int16))
+    dout = rnd(*out.shape, seed=15).cuda()
+    dg, db = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+    coef = ops.bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, 2, ops.BN_LEAKY, dgamma=dg, dbeta=db, beta=beta, coef_only=True)
+    dw = ops.conv3d_c1_wgrad_bn(x, y, dout, out, arg, mean, invstd, coef, 2, nchunk=5, precise=ops.MODE_BF16)
+    dw2 = ops.conv3d_c1_wgrad_bn_recompute(x, wgt, dout, arg, mean, invstd, beta, coef, 2, nchunk=5)
+    assert torch.equal(dw, dw2), (dw - dw2).abs().max().item()
+    # the reduction of the BatchNorm backward does not touch y when every |gamma| >= 1e-2: hand it the uninitialised tensor
+    dg2, db2 = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+    y2.fill_(float("nan"))
+    coef2 = ops.bn_pool_act_bwd(dout, o2, a2, y2, mean, invstd, gamma, 2, ops.BN_LEAKY, dgamma=dg2, dbeta=db2, beta=beta, coef_only=True)
+    assert torch.equal(coef, coef2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    # degenerate channel (|gamma| < 1e-2): the statistics pass stores y after all, and the gather path of the reduction reads it
+    gamma[5] = 1e-3
+    y3, part3 = ops.conv3d_c1_stats(x, wgt, gamma)
+    assert torch.equal(y3, y) and torch.equal(part3, part)
+
+
 def test_bn_pool_strided_output():
     """last visual stage writes the [B,16,T,S] block of the LSTM sequence buffer directly"""
     from maavss_amd import ops
