@@ -73,15 +73,18 @@ __global__ void conv3d_prep_w_kernel(const float* __restrict__ w, typename Mma<P
 // to HBM (PMC before: 3.1 GB fetched for a 0.79 GB input by the 32->16 dgrad, 3.3-3.9x on the other layers).  Here
 // XCD k walks the k-th contiguous eighth of the tile list, tx fastest, then ty, then bt, so those re-reads meet in L2.
 struct TileId { int tx, ty, bt; int64_t lin; bool valid; };
-__device__ __forceinline__ TileId xcd_tile(int nx, int ny, int64_t total) {
-  const int64_t per = (total + 7) / 8;
-  const int64_t lin = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+__device__ __forceinline__ TileId xcd_tile(int nx, int ny, int64_t total64) {
+  // 32-bit unsigned arithmetic (the host checks total < 2^31): every wave of a workgroup runs this on the CU's one scalar
+  // unit, and the 64-bit divisions of the first version were ~300 scalar instructions per wave
+  const unsigned total = (unsigned)total64, per = (total + 7) / 8;
+  const unsigned lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   TileId t;
-  t.valid = (int64_t)(blockIdx.x >> 3) < per && lin < total;
+  t.valid = (blockIdx.x >> 3) < per && lin < total;
   t.lin = lin;
-  t.tx = (int)(lin % nx);
-  t.ty = (int)((lin / nx) % ny);
-  t.bt = (int)(lin / ((int64_t)nx * ny));
+  const unsigned row = lin / (unsigned)nx;
+  t.tx = (int)(lin - row * (unsigned)nx);
+  t.bt = (int)(row / (unsigned)ny);
+  t.ty = (int)(row - (unsigned)t.bt * (unsigned)ny);
   return t;
 }
 static inline int xcd_grid(int64_t total) { return (int)(((total + 7) / 8) * 8); }
@@ -358,6 +361,7 @@ extern "C" int maavss_conv3d_igemm(const void* x, const void* wt, float* y, floa
   MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_igemm: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_igemm: empty output");
+  MAAVSS_CHECK_ARG((int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T < (1LL << 31) - 8, "conv3d_igemm: too many output tiles");
   const int KP = maavss_conv3d_kp(c_in);
   hipStream_t st = (hipStream_t)stream;
 #define CASE(CI, CO)                                                                                          \
