@@ -58,6 +58,17 @@ def test_round3_entry_points_validate_their_arguments_before_touching_the_device
     tiles = 14 * 14 * 32 * 16
     assert _lib.query("maavss_conv3d_c1_fwd_nparts", 32, 16, 224, 224, 2) == (tiles + 7) // 8
     assert _lib.query("maavss_conv3d_c1_fwd_nparts", 32, 16, 224, 224, 1) == tiles
+    # the first layer without its conv output: null operands and oversize problems are refused before any launch
+    with pytest.raises(_lib.MaavssError, match="conv3d_c1_stats"):
+        _lib.call("maavss_conv3d_c1_stats", 256, 256, None, 256, 256, 1, 1, 16, 16, None)
+    with pytest.raises(_lib.MaavssError, match="too many tiles"):
+        _lib.call("maavss_conv3d_c1_stats", 256, 256, 256, 256, 256, 1 << 15, 1 << 15, 1024, 1024, None)
+    with pytest.raises(_lib.MaavssError, match="conv3d_c1_bn_pool_act"):
+        _lib.call("maavss_conv3d_c1_bn_pool_act", 256, 256, 256, 256, 256, 256, 256, None, None, 1, 1, 16, 16, None)   # argmax is required
+    with pytest.raises(_lib.MaavssError, match="pool must be 2 or 3"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, 256, 256, 4, 256, 256, 8, 1, 1, 16, 16, 0, None)
+    with pytest.raises(_lib.MaavssError, match="null pointer"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, None, 256, 2, 256, 256, 8, 1, 1, 16, 16, 0, None)   # BatchNorm bias
     # deterministic switch: process-wide, returns the previous setting
     prev = _lib.query("maavss_set_deterministic", 1)
     assert _lib.query("maavss_get_deterministic") == 1
