@@ -6,6 +6,7 @@ written and re-loaded through the reference's own file layout (utilities.py:162-
 stream (ClipPipeline).
 
     python examples/train_synthetic.py [--steps 6] [--batch 4] [--num_frames 8] [--num_seq 3] [--framesize 256]
+    python examples/train_synthetic.py --overfit --steps 300 --lr 1e-4 --log_every 20     # one fixed batch: the loss has to fall
 """
 import argparse
 import os
@@ -28,6 +29,9 @@ def main():
     ap.add_argument("--fft_len", type=int, default=512)
     ap.add_argument("--hops_per_frame", type=int, default=8)
     ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--overfit", action="store_true", help="train on ONE fixed batch (same clips, same noise draw) every step")
+    ap.add_argument("--log_every", type=int, default=1)
+    ap.add_argument("--precise", action="store_true", help="exact-f32 conv path instead of the 16-bit MFMA modes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     b, nf, ns, w, hpf = a.batch, a.num_frames, a.num_seq, a.framesize, a.hops_per_frame
@@ -37,7 +41,7 @@ def main():
 
     extractor = maavss_amd.VideoAttention(path_to_weights="dino_deitsmall8_pretrain.pth")      # random init when absent (no network)
     stft = maavss_amd.STFT(a.fft_len, hop, noise_std=0.1, device=dev)
-    model = maavss_amd.AV_Fusion_Model_Frames([b, 2, hpf * nf, n_bins], [b, 1, nf, w, w], hpf).to(dev).train()
+    model = maavss_amd.AV_Fusion_Model_Frames([b, 2, hpf * nf, n_bins], [b, 1, nf, w, w], hpf, precise=a.precise).to(dev).train()
     step = maavss_amd.TrainStep(model, lr=a.lr, loss_coeff=0.001, num_seq=ns)
     pipe = maavss_amd.ClipPipeline(extractor, stft, clip_frames=t_total)
 
@@ -48,13 +52,15 @@ def main():
         audio = (0.3 * torch.randn(b, length, generator=g)).clamp(-1, 1)
         return frames.to(dev), audio.to(dev)
 
-    pipe.submit(*batch(), seed=0)
+    fixed = batch() if a.overfit else None
+    pipe.submit(*(fixed or batch()), seed=0)
     for i in range(a.steps):
-        pipe.submit(*batch(), seed=i + 1)                        # extraction of the next batch: side stream
+        pipe.submit(*(fixed or batch()), seed=0 if a.overfit else i + 1)      # extraction of the next batch: side stream
         attn, x_stft, y_stft = pipe.get()                        # [B,1,T,H,W], [B,2,T_a,F] x 2
         losses = step.sliding_window_step(x_stft, y_stft, attn, attn, nf, hpf)
         pipe.release()
-        print(f"step {i}: a_loss {losses[0].item():.5f}  v_loss {losses[1].item():.5f}  loss {losses[2].item():.5f}")
+        if i % a.log_every == 0 or i == a.steps - 1:
+            print(f"step {i}: a_loss {losses[0].item():.5f}  v_loss {losses[1].item():.5f}  loss {losses[2].item():.5f}", flush=True)
     pipe.drain()
 
     with tempfile.TemporaryDirectory() as cp_dir:
