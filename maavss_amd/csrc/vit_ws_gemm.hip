@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   float* bias_lds = reinterpret_cast<float*>(smem + WS_BUFS * WS_PANEL_BYTES);   // [384] (+ [384] gamma, [384] beta, stats)
   float* gam_lds = bias_lds + WS_SLICE;
   float* bet_lds = gam_lds + WS_SLICE;
-  float2* stat_lds = reinterpret_cast<float2*>(bet_lds + WS_SLICE);              // [64 rows][12 waves] (mean, M2) of 32 columns
+  float2* stat_lds = reinterpret_cast<float2*>(bet_lds + WS_SLICE);              // [12 waves][64 rows] (mean, M2) of 32 columns
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, half = lane >> 5;
   // workgroup -> (XCD, slot): dispatch is round-robin over the 8 XCDs, so blockIdx & 7 is the XCD
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -376,17 +376,20 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) { const float d = acc[e] - mu; m2 += d * d; }
           lane_swap32(m2, sa, sb);
-          float2* sp = stat_lds + (32 * h2 + r32) * WS_WAVES;
-          if (half == 0) sp[wv] = make_float2(mu, sa + sb);
+          // [wave][row]: the 32 rows of a lane group are consecutive 8-byte slots (conflict-free).  The first layout, [row][wave]
+          // with a 24-dword row stride, put rows r and r + 4 on the same banks: every one of these reads was an 8-way conflict,
+          // 48 % of the kernel's LDS cycles (profiles/r3_e_kernel_pmc.json) -- twice the panel's MFMA time on the CU's one LDS.
+          float2* sp = stat_lds + (32 * h2 + r32);
+          if (half == 0) sp[wv * WS_BM] = make_float2(mu, sa + sb);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           float mean = 0.f;
 #pragma unroll 4
-          for (int k = 0; k < WS_WAVES; ++k) mean += sp[k].x;
+          for (int k = 0; k < WS_WAVES; ++k) mean += sp[k * WS_BM].x;
           mean *= 1.f / WS_WAVES;
           float tot = 0.f;
 #pragma unroll 4
-          for (int k = 0; k < WS_WAVES; ++k) { const float2 st = sp[k]; const float d = st.x - mean; tot += st.y + 32.f * d * d; }
+          for (int k = 0; k < WS_WAVES; ++k) { const float2 st = sp[k * WS_BM]; const float d = st.x - mean; tot += st.y + 32.f * d * d; }
           const float rstd = rsqrtf(tot * (1.f / WS_K) + g.ln_eps);
           bf16_t* xp = g.XN + row * WS_K + n0 + 8 * half;
 #pragma unroll
