@@ -918,6 +918,10 @@ __global__ void conv3d_c1_prep_kernel(const float* __restrict__ w, float* __rest
 // FUSE_BN: `dy` is the pre-BatchNorm conv output y and the gradient is formed on the way into LDS from the pooled
 // gradient / output / argmax and the BatchNorm backward coefficients -- the bn_pool_act_bwd_dx pass of the first layer
 // (whose only consumer is this kernel: the network input needs no gradient) and its 1.6 GB dy round trip disappear.
+// x / pool for pool = 2 or 3 (x >= 0, x < 98304) without the runtime integer division (~25 vector instructions each, sixteen of them
+// per wave and tile in the first layer's weight-gradient kernels: 768 -> 697 us for the recompute kernel)
+__device__ __forceinline__ int c1_pdiv(int x, int pool) { return pool == 2 ? (x >> 1) : (int)(((unsigned)x * 43691u) >> 17); }
+
 struct C1BnArgs {
   const float* dout;            // [BT][Hp][Wp][16] gradient of the pooled, activated output
   const float* out;             // [BT][Hp][Wp][16] that output
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __res
         v = *reinterpret_cast<const float4*>(dy + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
         if constexpr (FUSE_BN) {
           // same arithmetic as bn_pool_act_bwd_dx_kernel (bn_pool.hip), LeakyReLU(0.01) + max pool
-          const int py = oy / bn.pool, px = ox / bn.pool;
+          const int py = c1_pdiv(oy, bn.pool), px = c1_pdiv(ox, bn.pool);
           float gg[4] = {0.f, 0.f, 0.f, 0.f};
           if (py < bn.Hp && px < bn.Wp) {
             const int64_t pp = (((int64_t)bt * bn.Hp + py) * bn.Wp + px) * 16 + cc;
@@ -1072,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int it = 0; it < 4; ++it) {
       const int i = tid + it * 256, pos = i >> 2, cc = (i & 3) * 4;
       const int oy = min(y0 + (pos >> 4), H - 1), ox = min(x0 + (pos & 15), W - 1);
-      const int py = min(oy / bn.pool, bn.Hp - 1), px = min(ox / bn.pool, bn.Wp - 1);
+      const int py = min(c1_pdiv(oy, bn.pool), bn.Hp - 1), px = min(c1_pdiv(ox, bn.pool), bn.Wp - 1);
       const int64_t pp = (((int64_t)bt * bn.Hp + py) * bn.Wp + px) * 16 + cc;
       yv[it] = *reinterpret_cast<const float4*>(yconv + (((int64_t)bt * H + oy) * W + ox) * 16 + cc);
       am[it] = *reinterpret_cast<const uchar4*>(bn.argmax + pp);
@@ -1093,7 +1097,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (oy < H && ox < W) {
         // same arithmetic as bn_pool_act_bwd_dx_kernel (bn_pool.hip), LeakyReLU(0.01) + max pool
-        const int py = oy / bn.pool, px = ox / bn.pool;
+        const int py = c1_pdiv(oy, bn.pool), px = c1_pdiv(ox, bn.pool);
         float gg[4] = {0.f, 0.f, 0.f, 0.f};
         if (py < bn.Hp && px < bn.Wp) {
           const int here = (oy - py * bn.pool) * bn.pool + (ox - px * bn.pool);
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_recompute_kernel(const fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int oy = min(y0 + 4 * wv + i, H - 1), ox = min(x0 + l16, W - 1);
-      const int py = min(oy / bn.pool, bn.Hp - 1), px = min(ox / bn.pool, bn.Wp - 1);
+      const int py = min(c1_pdiv(oy, bn.pool), bn.Hp - 1), px = min(c1_pdiv(ox, bn.pool), bn.Wp - 1);
       const int64_t pp = (((int64_t)cbt * bn.Hp + py) * bn.Wp + px) * 16 + 4 * g;
       am[i] = *reinterpret_cast<const uchar4*>(bn.argmax + pp);
       dv[i] = *reinterpret_cast<const float4*>(bn.dout + pp);
@@ -1235,7 +1239,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_recompute_kernel(const fl
       const int oy = y0 + 4 * wv + i, ox = x0 + l16, pos = (4 * wv + i) * 16 + l16;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (oy < H && ox < W) {
-        const int py = oy / bn.pool, px = ox / bn.pool;
+        const int py = c1_pdiv(oy, bn.pool), px = c1_pdiv(ox, bn.pool);
         float gg[4] = {0.f, 0.f, 0.f, 0.f};
         if (py < bn.Hp && px < bn.Wp) {
           const int here = (oy - py * bn.pool) * bn.pool + (ox - px * bn.pool);
