@@ -418,7 +418,7 @@ def main():
                        "parallelism": f"dp{world}", "streams": "2 (extraction of batch i+1 under the training step of batch i)" if pipe is not None else "1", "avse_spatial_match": spatial, "vit_weights": "random-init (no network)",
                        "vit": args.vit_dtype, "vit_attention": "block-scaled fp8 (MX e4m3, e8m0 scale per 32; f32 accumulate -- wider than the config's bf16)" if args.attn_dtype == "fp8" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
                        "end_to_end_mask_mse_vs_fp32_reference_chain": ("3.0e-3 ... 5.7e-3 over four seed sets (tests/test_parity_r2_gpu.py[fp8], tests/test_parity_r3_gpu.py, shape P; e4m3 operands: a throughput mode)" if args.attn_dtype == "fp8"
-                                                                    else ("4.6e-6" if args.vit_dtype == "f16" else "2.3e-4") + " (tests/test_parity_r2_gpu.py, shape P; target 1e-5)"),
+                                                                    else ("3.0e-6 ... 6.5e-6 over five seed sets, shape P and the benched shape" if args.vit_dtype == "f16" else "2.3e-4 (shape P)") + " (tests/test_parity_r2_gpu.py, tests/test_parity_r3_gpu.py; target 1e-5)"),
                        "linear_lstm": "f32" + (" (deterministic: no atomic split-K)" if args.deterministic else " (split-K by f32 atomics)"), "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank", "grad_all_reduce": f"{args.grad_wire} wire, per-module buckets in backward order",
                        "loss": loss_val},
             "roofline": roofline,
