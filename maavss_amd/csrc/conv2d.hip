@@ -43,6 +43,15 @@ __global__ __launch_bounds__(256) void conv2d_fwd_kernel(const float* __restrict
 template <int CO>
 __global__ __launch_bounds__(256) void conv2d_fwd_pos_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, C2Geom g) {
+  // Weights in LDS as [ci][kh][kw][CO]: the CO weights of a tap are CO / 4 broadcast 16-byte reads.  Straight from global memory they were CO
+  // scalar loads per tap -- 1.4 scalar-memory instructions per vector instruction, a quarter of the waves' cycles on the scalar unit
+  // (profiles/r3_f_scalar_pmc.json).  Same FMA order: results unchanged.
+  __shared__ __attribute__((aligned(16))) float wl[16 * 27 * CO];
+  for (int i = threadIdx.x; i < g.Ci * 27 * CO; i += 256) {
+    const int c = i % CO, t = i / CO;                  // t = ci * 27 + kh * 9 + kw
+    wl[i] = w[(int64_t)c * g.Ci * 27 + t];
+  }
+  __syncthreads();
   const int64_t npos = (int64_t)g.B * g.Ho * g.Wo;
   for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < npos; pos += (int64_t)gridDim.x * 256) {
     const int ox = (int)(pos % g.Wo), oy = (int)((pos / g.Wo) % g.Ho), b = (int)(pos / ((int64_t)g.Wo * g.Ho));
@@ -59,9 +68,13 @@ __global__ __launch_bounds__(256) void conv2d_fwd_pos_kernel(const float* __rest
           const int ix = ox * g.sw + kw - g.pw;
           float v = 0.f;
           if (oky && ix >= 0 && ix < g.W) v = x[in_index(g, b, ci, iy, ix)];
-          const float* wp = w + ((int64_t)ci * 3 + kh) * 9 + kw;        // + co * Ci * 27: wave-uniform -> scalar loads
+          const float4* wp = reinterpret_cast<const float4*>(wl + ((ci * 3 + kh) * 9 + kw) * CO);
 #pragma unroll
-          for (int c = 0; c < CO; ++c) acc[c] = fmaf(v, wp[(int64_t)c * g.Ci * 27], acc[c]);
+          for (int c = 0; c < CO; c += 4) {
+            const float4 w4 = wp[c / 4];
+            acc[c] = fmaf(v, w4.x, acc[c]); acc[c + 1] = fmaf(v, w4.y, acc[c + 1]);
+            acc[c + 2] = fmaf(v, w4.z, acc[c + 2]); acc[c + 3] = fmaf(v, w4.w, acc[c + 3]);
+          }
         }
       }
     float4* yp = reinterpret_cast<float4*>(y + pos * CO);
@@ -74,6 +87,13 @@ __global__ __launch_bounds__(256) void conv2d_fwd_pos_kernel(const float* __rest
 template <int CI>
 __global__ __launch_bounds__(256) void conv2d_dgrad_pos_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                float* __restrict__ dx, C2Geom g) {
+  // weights in LDS as [kh][kw][co][CI] (see conv2d_fwd_pos_kernel): the CI weights of (tap, co) are CI / 4 broadcast reads (CI = 2: one 8-byte read)
+  __shared__ __attribute__((aligned(16))) float wl[27 * 16 * CI];
+  for (int i = threadIdx.x; i < 27 * g.Co * CI; i += 256) {
+    const int c = i % CI, co = (i / CI) % g.Co, t = i / (CI * g.Co);      // t = kh * 9 + kw
+    wl[i] = w[((int64_t)co * CI + c) * 27 + t];
+  }
+  __syncthreads();
   const int64_t npos = (int64_t)g.B * g.H * g.W;
   for (int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x; pos < npos; pos += (int64_t)gridDim.x * 256) {
     const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), b = (int)(pos / ((int64_t)g.W * g.H));
@@ -98,9 +118,18 @@ __global__ __launch_bounds__(256) void conv2d_dgrad_pos_kernel(const float* __re
           const float dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float* wp = w + ((int64_t)(c4 * 4 + e) * CI * 3 + kh) * 9 + kw;    // + ci * 27: wave-uniform
+            const float* wp = wl + ((kh * 9 + kw) * g.Co + c4 * 4 + e) * CI;
+            if constexpr (CI % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < CI; ++c) acc[c] = fmaf(dd[e], wp[c * 27], acc[c]);
+              for (int c = 0; c < CI; c += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wp + c);
+                acc[c] = fmaf(dd[e], w4.x, acc[c]); acc[c + 1] = fmaf(dd[e], w4.y, acc[c + 1]);
+                acc[c + 2] = fmaf(dd[e], w4.z, acc[c + 2]); acc[c + 3] = fmaf(dd[e], w4.w, acc[c + 3]);
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CI; ++c) acc[c] = fmaf(dd[e], wp[c], acc[c]);
+            }
           }
         }
       }
@@ -256,7 +285,8 @@ extern "C" int maavss_conv2d_fwd(const float* x, const float* w, float* y, int B
   const int64_t total = (int64_t)B * g.Ho * g.Wo * Co, npos = (int64_t)B * g.Ho * g.Wo;
   const dim3 pgrid(min((int64_t)8192, (npos + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 4) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<4>, pgrid, dim3(256), 0, st, x, w, y, g);
+  if (Ci > 16) hipLaunchKernelGGL(conv2d_fwd_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, st, x, w, y, g);   // LDS weight image: C_in <= 16
+  else if (Co == 4) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<4>, pgrid, dim3(256), 0, st, x, w, y, g);
   else if (Co == 8) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<8>, pgrid, dim3(256), 0, st, x, w, y, g);
   else if (Co == 16) hipLaunchKernelGGL(conv2d_fwd_pos_kernel<16>, pgrid, dim3(256), 0, st, x, w, y, g);
   else hipLaunchKernelGGL(conv2d_fwd_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, st, x, w, y, g);
@@ -272,7 +302,8 @@ extern "C" int maavss_conv2d_dgrad(const float* dy, const float* w, float* dx, i
   const int64_t total = (int64_t)B * H * W * Ci, npos = (int64_t)B * H * W;
   const dim3 pgrid(min((int64_t)8192, (npos + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (Co % 4 == 0 && Ci == 2) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<2>, pgrid, dim3(256), 0, st, dy, w, dx, g);
+  if (Co > 16) hipLaunchKernelGGL(conv2d_dgrad_kernel, dim3(min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, st, dy, w, dx, g);   // LDS weight image: C_out <= 16
+  else if (Co % 4 == 0 && Ci == 2) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<2>, pgrid, dim3(256), 0, st, dy, w, dx, g);
   else if (Co % 4 == 0 && Ci == 4) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<4>, pgrid, dim3(256), 0, st, dy, w, dx, g);
   else if (Co % 4 == 0 && Ci == 8) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<8>, pgrid, dim3(256), 0, st, dy, w, dx, g);
   else if (Co % 4 == 0 && Ci == 16) hipLaunchKernelGGL(conv2d_dgrad_pos_kernel<16>, pgrid, dim3(256), 0, st, dy, w, dx, g);
