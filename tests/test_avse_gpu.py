@@ -369,3 +369,38 @@ def test_deterministic_mode_is_bit_reproducible():
     l3, p3 = run()                                       # default (atomic split-K) mode
     assert abs(l3[0] - l1[0]) <= 1e-6 * abs(l1[0]) + 1e-8
     assert (p3 - p1).norm().item() <= 1e-4 * p1.norm().item()
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_first_layer_without_its_conv_output_equals_the_storing_path_in_the_model(degenerate):
+    """The 16-bit training path never stores the first layer's conv output (three recompute passes); `c1_recompute=False`
+    selects the kernels that store and re-read it.  Same weights, same batch: outputs, every gradient and the BatchNorm running statistics
+    are BIT-IDENTICAL (deterministic mode).  degenerate: one first-layer BatchNorm weight below 1e-2 -- x-hat is then not recoverable from
+    the pooled output, the statistics pass stores y after all and the backward reduction gathers from it."""
+    import maavss_amd
+    m = dict(batch=2, frames=8, width=128, fft_len=256, hops_per_frame=8, seed=31)
+    prev = maavss_amd.set_deterministic(True)
+    try:
+        res = []
+        for recompute in (True, False):
+            model, _, (x_a, x_v, y_a, y_v) = _build(m, precise=False)
+            model.c1_recompute = recompute
+            if degenerate:
+                with torch.no_grad():
+                    model.visual_encoder[1].weight[5] = 2e-3
+            model.train()
+            a, v, f = model(x_a.cuda(), x_v.cuda())
+            loss = torch.nn.functional.mse_loss(a, y_a.cuda()) + 0.001 * torch.nn.functional.mse_loss(v, y_v.cuda())
+            loss.backward()
+            res.append((a.detach(), v.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                        {k: b.detach().clone() for k, b in model.named_buffers()}))
+    finally:
+        maavss_amd.set_deterministic(prev)
+    (a0, v0, g0, b0), (a1, v1, g1, b1) = res
+    assert torch.equal(a0, a1) and torch.equal(v0, v1)
+    assert g0.keys() == g1.keys() and len(g0) > 30
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max().item())
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    assert bool(torch.isfinite(g0["visual_encoder.1.weight"]).all()) and g0["visual_encoder.1.weight"].abs().max().item() > 0
