@@ -258,12 +258,22 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* __restri
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void conv2d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int n, int nchunk, int beta) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// 16 outputs x 16 chunk phases per 256-thread block (one thread per output walking up to 256 chunks serially was a chain of dependent
+// loads: 60 us for the 216 weights of the first layer); fixed summation order: deterministic
+__global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int n, int nchunk, int beta) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, ph = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
   float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += partials[(int64_t)c * n + i];
-  dw[i] = beta ? dw[i] + s : s;
+  if (i < n)
+    for (int c = ph; c < nchunk; c += 16) s += partials[(int64_t)c * n + i];
+  red[ph][o] = s;
+  __syncthreads();
+  if (ph == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][o];
+    dw[i] = beta ? dw[i] + t : t;
+  }
 }
 
 static int make_c2geom(const char* who, C2Geom* g, int B, int Ci, int H, int W, int Co, int sh, int sw, int pw, int in_layout) {
@@ -338,7 +348,7 @@ extern "C" int maavss_conv2d_wgrad(const float* x, const float* dy, float* dw, f
   else hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(Co * Ci, nchunk), dim3(256), 0, st, x, dy, ws, g, ppc);
   MAAVSS_LAUNCH_CHECK("conv2d_wgrad_kernel");
   const int n = Co * Ci * 27;
-  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dw, n, nchunk, beta);
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, dw, n, nchunk, beta);
   MAAVSS_LAUNCH_CHECK("conv2d_wgrad_reduce_kernel");
   return MAAVSS_OK;
 }
