@@ -54,8 +54,10 @@ def test_config3_16bit_modes_against_fp32_and_emulating_oracles():
 TRAJ_STEPS = 10
 
 
-@pytest.mark.parametrize("lr,precise,loss_tol,seed", [(1e-5, False, 1e-3, 53), (1e-4, False, 5e-3, 53), (1e-4, True, 5e-3, 53),
-                                                      (1e-5, False, 1e-3, 19)])       # seed 7 as well in profiles/r3_trajectory_seeds.log (1.6e-4)
+# The suite's wall time is CPU-oracle time (10 twin steps = 16 s per case), so only the gate VERDICT asked for runs here -- the reference's
+# lr = 1e-5 on two seeded problems.  Measured with the same function and recorded in profiles/r3_trajectory_seeds.log: seed 7 (1.6e-4), and at
+# lr = 1e-4 the 16-bit path (1.7e-3, gate 5e-3) next to the exact-f32 HIP path as control (1.1e-4): (1e-4, False, 5e-3, 53), (1e-4, True, 5e-3, 53).
+@pytest.mark.parametrize("lr,precise,loss_tol,seed", [(1e-5, False, 1e-3, 53), (1e-5, False, 1e-3, 19)])
 def test_ten_step_trajectory_of_the_16bit_path_follows_the_fp32_twin(lr, precise, loss_tol, seed):
     """10 x (forward, loss, backward, Adam) on the pinned shape P, the same batch every step (train_avse_frames.py:150-181 with
     num_seq = 1): default 16-bit HIP TrainStep vs the fp32 oracle twin + torch.optim.Adam.  lr = 1e-5 is the reference's
