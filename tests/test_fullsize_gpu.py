@@ -16,7 +16,6 @@ against the oracle, in this file and in the per-stage suites.
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
