@@ -10,6 +10,8 @@ Inputs are generated once and are resident in HBM before the timed region (SURVE
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W          # one rank per GPU, weak scaling (B clips per GPU)
+    python bench.py --gpus N --steps K --warmup W       # no launcher: bench.py starts the N ranks itself (child processes,
+                                                        # before anything touches the GPU) and relays rank 0's JSON line
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed
 over the timed region) and `cpu_baseline` (the CPU oracle = validated port of the reference path, timed on the
@@ -26,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0      # dense block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): the roof of `--attn-dtype fp8` attention
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,6 +56,7 @@ def parse():
     ap.add_argument("--pipeline", choices=["on", "off"], default="on",
                     help="on: attention-frame extraction + STFT of batch i+1 on a second HIP stream under the training step of batch i "
                          "(maavss_amd.ClipPipeline; the reference's data path has no dependency on the optimizer step); off: one stream")
+    ap.add_argument("--rank-echo", choices=["ok", "fail"], default=None, help=argparse.SUPPRESS)   # launcher self-test, no GPU work
     ap.add_argument("--vit-dtype", choices=["f16", "bf16"], default="f16",
                     help="16-bit storage / MFMA operand format of the ViT extractor (same MFMA rate; f16 meets the 1e-5 mask-MSE end to end)")
     return ap.parse_args()
@@ -114,7 +118,9 @@ def cpu_baseline(args):
     med = statistics.median(times)
     return {"value": 1.0 / med, "unit": "clips/s", "cores": cores, "cores_note": f"cgroup quota / affinity of this job; os.cpu_count()={os.cpu_count()}",
             "kind": "port",
-            "sample": f"fp32 torch CPU oracle, batch 1, whole clips: ViT-S/8 attention frames of all {t} {w}x{w} frames + "
+            "batch": b,
+            "sample": f"fp32 torch CPU oracle, BATCH 1 (BASELINE.md section 4 planned the B = 32 shapes; one clip at a time is what fits the ~25 s budget -- "
+                      f"the ViT, 85 % of the work, runs its {t} frames as one batch either way), whole clips: ViT-S/8 attention frames of all {t} {w}x{w} frames + "
                       f"{args.fft_len}-pt STFT + noise + AVSE fwd/bwd/Adam; {warm} warm-ups, median of {len(times)} timed clips "
                       f"({med:.2f} s/clip, min {min(times):.2f}, max {max(times):.2f})"}
 
@@ -137,19 +143,66 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def launch_ranks(n, argv=None, env=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one rank each (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's stdout (the ONE JSON line),
+    return the worst exit status.  Runs before this process has imported torch or touched the GPU; children are spawned, never
+    exec'ed into."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MAAVSS_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    status = 0
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            status = max(status, abs(p.wait(timeout=timeout)))
+    except subprocess.TimeoutExpired:
+        status = 124
+    finally:
+        for p in procs:                      # a rank that died leaves the others in a collective: end exactly the PIDs started here
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                status = status or 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return status
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE (launch with torch.distributed.run)",
-              file=sys.stderr)
+    if args.rank_echo:                      # launcher self-test (tests/test_bench_launcher_cpu.py): no torch, no GPU
+        if args.rank_echo == "fail" and rank == world - 1:
+            sys.exit(3)
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": int(os.environ.get("MASTER_PORT", "0")), "self_launched": os.environ.get("MAAVSS_BENCH_SELF_LAUNCHED") == "1"}))
+        return
+    import torch
+    import torch.distributed as dist
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or run plain `python bench.py --gpus {args.gpus}` (bench.py then starts the ranks itself)")
     # Rehearsal knobs for a box with fewer GPUs than ranks (never used by the driver): all ranks on device 0
     # and/or the gloo backend.  The collective code path (trainer.GradSync) is the same.
     if os.environ.get("MAAVSS_BENCH_SINGLE_DEVICE") == "1":
@@ -237,6 +290,24 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = el.item()
     loss_val = float(losses[2].item())
+    # N > 1: evidence that the collective saw N ranks and kept the replicas identical -- every rank's parameter checksum
+    # (f64 sum and sum of squares of the flat buffer after the K timed Adam steps), MIN- and MAX-reduced over the ranks
+    collective = None
+    if world > 1:
+        pf = step_fn.flat.params.double()
+        cs = torch.stack([pf.sum(), (pf * pf).sum()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                       # every rank contributes 1: the sum IS the number of ranks that took part
+        collective = {"backend": dist.get_backend(), "ranks_seen": int(dist.get_world_size()), "ranks_summed": int(round(ones.item())),
+                      "replica_checksum_equal": bool(torch.equal(lo, hi)), "replica_checksum": [float(x) for x in cs.tolist()],
+                      "gpus_visible": int(torch.cuda.device_count()),
+                      "devices": "all ranks on cuda:0 (rehearsal)" if os.environ.get("MAAVSS_BENCH_SINGLE_DEVICE") == "1" else "one per rank",
+                      "launcher": "bench.py (self-launched child processes)" if os.environ.get("MAAVSS_BENCH_SELF_LAUNCHED") == "1" else "external (torch.distributed.run)",
+                      "grad_bytes_per_step": int(step_fn.flat.total * (2 if args.grad_wire == "bf16" else 4)),
+                      "buckets_launched_last_step": list(step_fn.sync.launch_log)}
     if pipe is not None:
         pipe.drain()
     va.check_finite()                        # the deferred range flags of the last steps
@@ -311,13 +382,14 @@ def main():
                 gbs = by / d["calls"] / (avg_ms * 1e-3) / 1e9
                 # the binding roof is the one under which this launch would take longer (K = 384 layers: 230 FLOP per
                 # algorithmic byte, below the chip's 2500 / 8 = 312 FLOP/B -> HBM; attention: 400 FLOP/B -> MFMA)
-                hbm_bound = by / (PEAK_HBM_GBS * 1e9) > fl / (PEAK_BF16_TFLOPS * 1e12)
+                mfma_peak = PEAK_FP8_TFLOPS if name == "maavss_vit_attn_mx" else PEAK_BF16_TFLOPS
+                hbm_bound = by / (PEAK_HBM_GBS * 1e9) > fl / (mfma_peak * 1e12)
                 roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
-                            "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                            "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else mfma_peak,
                             "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                            "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tf / mfma_peak, 4), "traffic": None,
                             "algorithmic_bytes_per_launch": round(by / d["calls"]), "algorithmic_flops_per_launch": round(fl / d["calls"]),
-                            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                            "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / mfma_peak, 4),
                             "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
                             "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                             "share_of_event_timed_entry_points": round(d["ms"] / sum(x["ms"] for x in summ.values()), 3),
@@ -332,7 +404,7 @@ def main():
                         us = dt["ms"] / dt["calls"] * 1e3
                         gbs_t, tf_t = by / d["calls"] / (us * 1e-6) / 1e9, fl / d["calls"] / (us * 1e-6) / 1e12
                         roofline["in_timed_region"] = {"avg_launch_us": round(us, 2), "achieved": round(gbs_t if hbm_bound else tf_t, 2),
-                                                       "frac": round(gbs_t / PEAK_HBM_GBS if hbm_bound else tf_t / PEAK_BF16_TFLOPS, 4)}
+                                                       "frac": round(gbs_t / PEAK_HBM_GBS if hbm_bound else tf_t / mfma_peak, 4)}
                 break
         # ---- the stages BASELINE.json's north star names explicitly: attention against the MFMA peak, the STFT path and
         # the other streaming kernels against HBM (algorithmic work / HIP-event time of the timed region)
@@ -344,7 +416,11 @@ def main():
             sec = d["ms"] * 1e-3
             row = {"ms_per_step": round(d["ms"] / args.steps, 3), "launches_per_step": d["calls"] // args.steps}
             if flops:
-                row.update(tflops=round(flops / sec / 1e12, 1), mfma_frac=round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4))
+                # a kernel is priced against the peak of the instruction it issues: fp8 attention against 5 PF
+                peak = PEAK_FP8_TFLOPS if name == "maavss_vit_attn_mx" else PEAK_BF16_TFLOPS
+                row.update(tflops=round(flops / sec / 1e12, 1), mfma_frac=round(flops / sec / 1e12 / peak, 4), mfma_peak_tflops=peak)
+                if peak != PEAK_BF16_TFLOPS:
+                    row["mfma_frac_of_bf16_peak"] = round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4)
             if bytes_:
                 row.update(gbs=round(bytes_ / sec / 1e9, 1), hbm_frac=round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4))
             stages[name.replace("maavss_", "")] = row
@@ -427,6 +503,8 @@ def main():
         }
         if timer_serial is not None:
             out["kernel_ms_per_step_in_timed_region"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(summ_timed.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        if collective is not None:
+            out["collective"] = collective
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -25,6 +25,14 @@
 extern "C" {
 #endif
 
+/* ABI version = what maavss_version() of a matching library returns; bumped whenever an entry point is removed or changes
+ * meaning (INTEGRATION.md "ABI history").  maavss_amd/_lib.py refuses a library whose version differs from this header's.
+ *   100  rounds 1-2
+ *   300  round 3: maavss_vit_attn_fp8{,_ws_bytes} removed (-> maavss_vit_attn_mx*); maavss_conv3d_c1_fwd(precise = 2) writes one
+ *        stat_partials row per 8-tile workgroup (maavss_conv3d_c1_fwd_nparts), not one per tile; the Philox counter layout of
+ *        maavss_stft_fwd's in-kernel noise changed (same seed, different noise)
+ *   400  round 4: maavss_set_deterministic_workspace takes the stream the scratch is bound to; see INTEGRATION.md */
+#define MAAVSS_ABI_VERSION 400
 const char* maavss_last_error(void);
 int maavss_version(void);
 const char* maavss_arch(void);
@@ -66,8 +74,9 @@ int maavss_get_deterministic(void);
 /* Optional device scratch (16-byte aligned; the library never allocates) that lets deterministic mode keep the K split of the
  * M = batch Linear forms: slices write partial sums [slices][32][cols], a second kernel adds them in slice order.  8.4 MB covers the
  * reference shapes (fc1 8192 -> 4096 at 512-wide slices); shapes that need more fall back to one slice per output element.  One
- * scratch per process: do not run Linear kernels of different streams concurrently in this mode.  NULL removes it. */
-int maavss_set_deterministic_workspace(float* ws, int64_t bytes);
+ * scratch per process, bound to `stream`: Linear kernels launched on any other stream do not use it (single-slice path), so
+ * two streams cannot race on it (ABI 400; before: no stream argument and no guard).  NULL removes it. */
+int maavss_set_deterministic_workspace(float* ws, int64_t bytes, void* stream);
 int maavss_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                     int64_t ldc, int transC, int64_t M, int64_t N, int64_t K, float alpha, int beta, int act,
                     int split_k, int precise, void* stream);

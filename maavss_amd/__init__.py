@@ -19,13 +19,15 @@ from . import attn_cache  # noqa: F401
 _det_ws = None
 
 
-def set_deterministic(on=True, workspace_mb=32):
+def set_deterministic(on=True, workspace_mb=32, stream=None):
     """Process-wide: no f32-atomic accumulation in the Linear / GEMM kernels (bit-identical runs; include/maavss.h).  A device scratch
     of `workspace_mb` MB is handed to the library so that the M = batch Linear forms keep their split over K (partial sums + an ordered
-    reduction) instead of streaming the weights through one slice.  Returns the previous setting."""
+    reduction) instead of streaming the weights through one slice.  The scratch is bound to `stream` (default: the current stream at the first
+    call, i.e. the training stream): Linear kernels on other streams take the single-slice path.  Returns the previous setting."""
     global _det_ws
     import torch
     if on and _det_ws is None and torch.cuda.is_available():
         _det_ws = torch.empty(workspace_mb * 262144, device="cuda", dtype=torch.float32)
-        _lib.call("maavss_set_deterministic_workspace", _det_ws.data_ptr(), _det_ws.numel() * 4)
+        st = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        _lib.call("maavss_set_deterministic_workspace", _det_ws.data_ptr(), _det_ws.numel() * 4, st)
     return bool(_lib.query("maavss_set_deterministic", int(bool(on))))

@@ -17,6 +17,13 @@ _SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c
             "float": ctypes.c_float, "double": ctypes.c_double, "uint32_t": ctypes.c_uint32}
 
 
+def header_abi_version(path=HEADER):
+    m = re.search(r"#define\s+MAAVSS_ABI_VERSION\s+(\d+)", open(path).read())
+    if not m:
+        raise MaavssError(f"{path}: no MAAVSS_ABI_VERSION")
+    return int(m.group(1))
+
+
 def parse_header(path=HEADER):
     """-> {name: (restype, [(argtype, argname)])} for every prototype in the header."""
     text = open(path).read()
@@ -56,6 +63,10 @@ class _Lib:
             fn = getattr(self.cdll, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = [t for t, _ in args]
+        have, want = self.cdll.maavss_version(), header_abi_version()
+        if have != want:
+            raise MaavssError(f"{LIB_PATH} reports ABI version {have}, include/maavss.h declares {want}: stale build "
+                              f"(entry points changed meaning between versions, see INTEGRATION.md) -- rebuild with `make -C maavss_amd/csrc`")
 
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)

@@ -10,7 +10,7 @@
 
 void maavss_set_error(const char* fmt, ...);
 int maavss_deterministic_flag(void);
-float* maavss_deterministic_ws(int64_t* floats);   // scratch for deterministic split-K partials (null if none was provided)   // api_core.hip: 1 = no atomic accumulation anywhere (maavss_set_deterministic)
+float* maavss_deterministic_ws(int64_t* floats, void* stream);   // api_core.hip: scratch for deterministic split-K partials (null if none was provided for `stream`)
 
 #define MAAVSS_CHECK_ARG(cond, ...)            \
   do {                                         \

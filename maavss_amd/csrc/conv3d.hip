@@ -1378,6 +1378,7 @@ extern "C" int maavss_conv3d_c1_wgrad(const float* x, const float* dy, float* dw
                                       int H, int W, int beta, void* stream) {
   MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_c1_wgrad: null pointer");
   MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0, "conv3d_c1_wgrad: bad sizes");
+  MAAVSS_CHECK_ARG(H > 0 && W > 0 && (int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31), "conv3d_c1_wgrad: empty image or too many tiles");
   return c1_wgrad_launch(x, dy, dw, ws, nchunk, B, T, H, W, beta, nullptr, (hipStream_t)stream);
 }
 
@@ -1388,6 +1389,10 @@ extern "C" int maavss_conv3d_c1_wgrad_bn_recompute(const float* x, const float* 
                                                    float* dw, float* ws, int nchunk, int B, int T, int H, int W, int beta, void* stream) {
   MAAVSS_CHECK_ARG(x && w && dout && argmax && mean && invstd && bn_beta && coef && dw && ws, "conv3d_c1_wgrad_bn_recompute: null pointer");
   MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn_recompute: bad sizes (pool must be 2 or 3)");
+  // H / pool >= 1 (the kernel clamps pooled indices to Hp - 1), c1_pdiv's multiply-shift division by 3 holds for x < 98304, the
+  // tile count is an int
+  MAAVSS_CHECK_ARG(H >= pool && W >= pool && H < 98304 && W < 98304, "conv3d_c1_wgrad_bn_recompute: H, W must be in [pool, 98304) (got %d x %d)", H, W);
+  MAAVSS_CHECK_ARG((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31), "conv3d_c1_wgrad_bn_recompute: too many tiles");
   C1BnArgs bn;
   bn.dout = dout; bn.out = nullptr; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
   bn.beta = bn_beta; bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;
@@ -1407,6 +1412,8 @@ extern "C" int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const f
   MAAVSS_CHECK_ARG(x && y && dout && out && argmax && mean && invstd && coef && dw && ws, "conv3d_c1_wgrad_bn: null pointer");
   MAAVSS_CHECK_ARG(precise == MODE_F32 || precise == MODE_BF16, "conv3d_c1_wgrad_bn: mode must be 1 (exact f32 VALU) or 0 (bf16 MFMA)");
   MAAVSS_CHECK_ARG(nchunk >= 1 && B > 0 && T > 0 && pool >= 2 && pool <= 3, "conv3d_c1_wgrad_bn: bad sizes (pool must be 2 or 3)");
+  MAAVSS_CHECK_ARG(H >= pool && W >= pool && H < 98304 && W < 98304 && (int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31),
+                   "conv3d_c1_wgrad_bn: H, W must be in [pool, 98304) and the tile count below 2^31 (got %d x %d)", H, W);
   C1BnArgs bn;
   bn.dout = dout; bn.out = out; bn.argmax = (const unsigned char*)argmax; bn.mean = mean; bn.invstd = invstd; bn.coef = coef;
   bn.beta = nullptr; bn.pool = pool; bn.Hp = H / pool; bn.Wp = W / pool;

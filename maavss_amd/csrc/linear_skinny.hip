@@ -245,7 +245,7 @@ int maavss_linear_skinny_try(const float* A, int64_t lda, int transA, const floa
   // deterministic mode: multi-slice cases are taken only when the caller provided scratch for the partial sums
   const bool det = maavss_deterministic_flag() != 0;
   int64_t ws_floats = 0;
-  float* det_ws = maavss_deterministic_ws(&ws_floats);
+  float* det_ws = maavss_deterministic_ws(&ws_floats, (void*)st);
   auto det_ok = [&](int64_t reduce_len, int slice_len, int64_t cols) { return !det || reduce_len <= slice_len || (det_ws && (int64_t)cdiv(reduce_len, slice_len) * 32 * cols <= ws_floats); };
   if (!transA && !transB && det_ok(K, LS_KS, N) && M <= 32 && N >= 512 && N % 4 == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
       aligned16(A) && aligned16(B) && aligned16(C)) {

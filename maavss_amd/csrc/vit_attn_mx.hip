@@ -305,6 +305,7 @@ extern "C" int maavss_vit_qkv_mx(const void* qkv, void* ws, int64_t rows, int ld
   MAAVSS_CHECK_ARG(qkv && ws && rows > 0 && ld_qkv >= 3 * MX_DIM, "vit_qkv_mx: bad arguments");
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_qkv_mx: dtype (of qkv) must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vit_qkv_mx: ws must be 256-byte aligned");
+  MAAVSS_CHECK_ARG(mx_ws_bytes(rows) < (1LL << 32), "vit_qkv_mx: %ld rows: workspace beyond the attention kernel's 32-bit offsets", (long)rows);
   const MxImages m = mx_images(ws, rows);
   const unsigned nb = (unsigned)(m.rows_alloc / 32);        // all allocated row blocks: the tail becomes exact zeros
   if (dtype == MODE_F16) hipLaunchKernelGGL(vit_qkv_mx_kernel<MODE_F16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, m, rows, ld_qkv);
@@ -319,6 +320,9 @@ extern "C" int maavss_vit_attn_mx(const void* ws, void* out, int frames, int nto
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_attn_mx: dtype (of out) must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vit_attn_mx: ws must be 256-byte aligned");
   const int64_t rows = (int64_t)frames * ntok;
+  // the kernel addresses the workspace with 32-bit byte offsets
+  MAAVSS_CHECK_ARG(mx_ws_bytes(rows) < (1LL << 32), "vit_attn_mx: %ld rows need a workspace of %ld bytes; the kernel's offsets are 32-bit (launch fewer frames per group)",
+                   (long)rows, (long)mx_ws_bytes(rows));
   const MxImages m = mx_images(const_cast<void*>(ws), rows);
   const int qblocks = cdiv(ntok, MXA_QT), ngroups = frames * heads;
   const int nblocks = cdiv(ngroups, 8) * 8 * qblocks;

@@ -287,7 +287,10 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           if (!(abl & 4)) {
             if constexpr (SWAPPED) Mma32<MODE>::mma(acc, f[kb % (WS_DEPTH + 1)], w[kb]);
             else Mma32<MODE>::mma(acc, w[kb], f[kb % (WS_DEPTH + 1)]);
-          } else if (kb == 23) acc[0] += (float)(f[0][0] + f[1][1] + f[2][2] + f[3][3]);
+          } else if (kb == 23) {   // measurement builds: keep every fragment register live (WS_DEPTH + 1 of them, not a fixed four)
+#pragma unroll
+            for (int i = 0; i <= WS_DEPTH; ++i) acc[0] += (float)f[i][i];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -510,6 +513,7 @@ extern "C" int maavss_vit_ws_gemm_ln_mx(const float* X, int64_t x_rows, const fl
   MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm_ln_mx: X needs ceil(M/64)*64 = %ld allocated rows (got %ld): whole panels are read",
                    (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows);
   MAAVSS_CHECK_ARG(qscale_cols % WS_SLICE == 0 && ((uintptr_t)mx_ws & 255) == 0, "vit_ws_gemm_ln_mx: qscale_cols must be a multiple of 384, mx_ws 256-byte aligned");
+  MAAVSS_CHECK_ARG(mx_ws_bytes(M) < (1LL << 32), "vit_ws_gemm_ln_mx: %ld rows: workspace beyond the attention kernel's 32-bit offsets (launch fewer frames per group)", (long)M);
   return ws_gemm_launch("vit_ws_gemm_ln_mx", nullptr, X, row_stats, W, bias, mx_ws, 3 * WS_SLICE, M, 3 * WS_SLICE, 3, qscale_cols, qscale, nullptr,
                         ln_gamma, ln_beta, ln_eps, dtype, stream, mx_ws);
 }

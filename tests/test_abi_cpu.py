@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, name), f"{name} declared in include/maavss.h but not exported"
     L = _lib.lib()
     assert L.cdll.maavss_arch() == b"gfx950"
-    assert L.cdll.maavss_version() >= 100
+    assert L.cdll.maavss_version() == _lib.header_abi_version() == 400
 
 
 def test_no_cpu_fallback():
@@ -75,5 +75,29 @@ def test_round3_entry_points_validate_their_arguments_before_touching_the_device
     assert _lib.query("maavss_set_deterministic", prev) == 1
     assert _lib.query("maavss_get_deterministic") == prev
     with pytest.raises(_lib.MaavssError, match="aligned"):
-        _lib.call("maavss_set_deterministic_workspace", 260, 1024)
-    _lib.call("maavss_set_deterministic_workspace", None, 0)
+        _lib.call("maavss_set_deterministic_workspace", 260, 1024, None)
+    _lib.call("maavss_set_deterministic_workspace", None, 0, None)
+
+
+def test_round4_argument_checks():
+    """the first-layer weight-gradient entry points refuse images smaller than the pool window / beyond the kernel's
+    index arithmetic, the fp8 attention refuses workspaces beyond its 32-bit offsets -- all before any launch."""
+    with pytest.raises(_lib.MaavssError, match=r"H, W must be in \[pool, 98304\)"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, 256, 256, 3, 256, 256, 8, 1, 1, 2, 16, 0, None)      # H < pool
+    with pytest.raises(_lib.MaavssError, match=r"H, W must be in \[pool, 98304\)"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, 256, 256, 3, 256, 256, 8, 1, 1, 16, 98304, 0, None)
+    with pytest.raises(_lib.MaavssError, match="too many tiles"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, 256, 256, 2, 256, 256, 8, 1 << 12, 1 << 12, 4096, 4096, 0, None)
+    with pytest.raises(_lib.MaavssError, match="H, W must be in"):
+        _lib.call("maavss_conv3d_c1_wgrad_bn", 256, 256, 256, 256, 256, 256, 256, 256, 2, 256, 256, 8, 1, 1, 1, 16, 0, 0, None)
+    with pytest.raises(_lib.MaavssError, match="empty image or too many tiles"):
+        _lib.call("maavss_conv3d_c1_wgrad", 256, 256, 256, 256, 8, 1 << 12, 1 << 12, 4096, 4096, 0, None)
+    # 4 608 frames x 785 tokens: 3 * rows_alloc * 384 > 2^32
+    rows = 4608 * 785
+    assert _lib.query("maavss_vit_attn_mx_ws_bytes", rows) >= 1 << 32
+    with pytest.raises(_lib.MaavssError, match="32-bit"):
+        _lib.call("maavss_vit_attn_mx", 256, 256, 4608, 785, 6, 384, 2, None)
+    with pytest.raises(_lib.MaavssError, match="32-bit"):
+        _lib.call("maavss_vit_qkv_mx", 256, 256, rows, 1152, 2, None)
+    with pytest.raises(_lib.MaavssError, match="32-bit"):
+        _lib.call("maavss_vit_ws_gemm_ln_mx", 256, (rows + 63) // 64 * 64, 256, 256, 256, 1e-6, 256, 256, 256, rows, 384, 1.0, 2, None)

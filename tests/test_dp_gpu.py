@@ -132,3 +132,27 @@ def test_bf16_wire_format_of_the_gradient_all_reduce(tmp_path):
         assert err <= 6e-3, (n, err)            # bf16: 2^-9 per operand and per sum, rms over the tensor
         assert (b16[0]["grads"][n] - g).abs().max().item() <= 2.0 ** -7 * g.abs().max().item() + 1e-12, n
     print(f"[dp] bf16 wire vs f32 wire: worst gradient tensor relative L2 {worst:.2e}")
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself and the N > 1 line proves the
+    collective saw them: n_gpus 2, ranks_seen / ranks_summed 2, parameter checksums equal on both ranks after the timed Adam
+    steps.  Rehearsal form for a one-GPU box: both ranks on cuda:0, gloo (the code path of trainer.GradSync is the same)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MAAVSS_BENCH_SINGLE_DEVICE="1", MAAVSS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "8",
+           "--framesize", "128", "--fft_len", "256", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["ranks_summed"] == 2
+    assert c["replica_checksum_equal"] is True
+    assert c["launcher"].startswith("bench.py")
+    assert c["buckets_launched_last_step"] == ["a_fc1", "v_fc1", "fc2", "fc1", "lstm", "encoders"]
+    assert "cpu_baseline" not in d                     # N = 1 only
