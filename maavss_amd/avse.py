@@ -190,6 +190,10 @@ class AV_Fusion_Model_Frames(nn.Module):
         self.latent_channels = latent_channels
         self.output_stft_frames = hops_per_frame
         self.precise = bool(precise)
+        # The two halves of `precise`, separately switchable for parity isolation (tests/test_parity_r4_gpu.py: exact-f32 forward with
+        # the bf16 backward gates the 16-bit backward kernels at model level; the 16-bit forward's MaxPool / LeakyReLU re-routing is
+        # then out of the picture).  `precise=` sets both; product code never sets them apart.
+        self.precise_fwd = self.precise_bwd = self.precise
         # 16-bit path: the first layer's conv output is recomputed instead of stored (MAAVSS_C1_RECOMPUTE=0: the storing kernels, for A/B)
         self.c1_recompute = os.environ.get("MAAVSS_C1_RECOMPUTE", "1") != "0"
         self._bn_sync = None
@@ -474,7 +478,7 @@ class AV_Fusion_Model_Frames(nn.Module):
 
     def _engine_forward(self, x_a, x_v, train=True):
         # train=False (model.eval()): BatchNorm uses its running statistics and leaves them untouched (forward only)
-        pr = ops.MODE_F32 if self.precise else ops.MODE_F16     # forward conv operands: IEEE half (or exact f32)
+        pr = ops.MODE_F32 if self.precise_fwd else ops.MODE_F16     # forward conv operands: IEEE half (or exact f32)
         b, t, w = x_v.shape[0], self.t_v, self.width
         assert tuple(x_v.shape[1:]) == (1, t, w, w) and tuple(x_a.shape[1:]) == (2, self.t_a, self.n_bins)
         x_v = x_v.contiguous().float()
@@ -493,7 +497,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
             # 16-bit first layer, training forward: the conv output (the step's largest tensor) is never stored -- pass 1 its
             # BatchNorm sums, pass 2 conv again -> BatchNorm -> pool -> LeakyReLU, and the weight gradient recomputes it per tile
-            recompute = i == 0 and train and not self.precise and pool == 2 and self.c1_recompute
+            recompute = i == 0 and train and not self.precise_fwd and pool == 2 and self.c1_recompute
             if recompute:
                 y, part = ops.conv3d_c1_stats(act_in, conv.weight.detach(), bn.weight.detach())
             elif i == 0:
@@ -511,7 +515,7 @@ class AV_Fusion_Model_Frames(nn.Module):
                 out, arg, act_in16 = ops.conv3d_c1_bn_pool_act(act_in, conv.weight.detach(), mean, invstd, bn.weight.detach(), bn.bias.detach())
                 strides = None
             elif i < 4:
-                if self.precise:
+                if self.precise_fwd:
                     out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
                 else:
                     out, arg, act_in16 = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
@@ -570,7 +574,7 @@ class AV_Fusion_Model_Frames(nn.Module):
         after each of those weight gradients has been enqueued (trainer.GradSync launches its buckets from it: the heads'
         all-reduce starts while fc2 / fc1 / the LSTM are still in their backward pass)."""
         # conv backward operands: bf16 (gradients need the exponent range), or exact f32; Linear layers always f32
-        pr_conv, pr = (ops.MODE_F32 if self.precise else ops.MODE_BF16), ops.MODE_F32
+        pr_conv, pr = (ops.MODE_F32 if self.precise_bwd else ops.MODE_BF16), ops.MODE_F32
         bn_reduce = _bn_eval_reduce if bn_eval else self._bn_sync       # `bn_eval`: the forward used running statistics
         out_grads = {}
         pd = dict(self.named_parameters())
@@ -690,7 +694,7 @@ class AV_Fusion_Model_Frames(nn.Module):
             # 16-bit path: dy is written as bf16 -- what both of its consumers (weight gradient, input gradient) round it to
             dy = ops.bn_pool_act_bwd(dout, out, s["arg"], s["y"], s["mean"], s["invstd"], bn.weight.detach(), pool,
                                      ops.BN_LEAKY, strides=s["strides"], dgamma=gw, dbeta=gb, accumulate=acc, beta=bn.bias.detach(),
-                                     reduce_fn=bn_reduce, dy_bf16=not self.precise)
+                                     reduce_fn=bn_reduce, dy_bf16=not self.precise_bwd)
             if need.get(wname, False):
                 buf, beta = gbuf(wname)
                 if i == 0:

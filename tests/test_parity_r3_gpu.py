@@ -57,7 +57,12 @@ TRAJ_STEPS = 10
 # The suite's wall time is CPU-oracle time (10 twin steps = 16 s per case), so only the gate VERDICT asked for runs here -- the reference's
 # lr = 1e-5.  Measured with the same function and recorded in profiles/r3_trajectory_seeds.log: seed 7 (1.6e-4), and at
 # lr = 1e-4 the 16-bit path (1.7e-3, gate 5e-3) next to the exact-f32 HIP path as control (1.1e-4): (1e-4, False, 5e-3, 53), (1e-4, True, 5e-3, 53).
-@pytest.mark.parametrize("lr,precise,loss_tol,seed", [(1e-5, False, 1e-3, 53)])          # seed 19: 2.0e-4, same log
+@pytest.mark.parametrize("lr,precise,loss_tol,seed", [
+    (1e-5, False, 1e-3, 53),
+    pytest.param(1e-5, False, 1e-3, 19, marks=pytest.mark.slow),          # 2.0e-4 (profiles/r3_trajectory_seeds.log)
+    pytest.param(1e-4, False, 5e-3, 53, marks=pytest.mark.slow),          # 1.7e-3
+    pytest.param(1e-4, True, 5e-3, 53, marks=pytest.mark.slow),           # the exact-f32 control: 1.1e-4
+])
 def test_ten_step_trajectory_of_the_16bit_path_follows_the_fp32_twin(lr, precise, loss_tol, seed):
     """10 x (forward, loss, backward, Adam) on the pinned shape P, the same batch every step (train_avse_frames.py:150-181 with
     num_seq = 1): default 16-bit HIP TrainStep vs the fp32 oracle twin + torch.optim.Adam.  lr = 1e-5 is the reference's
@@ -111,6 +116,8 @@ def _trajectory(maavss_amd, orc, lr, precise, loss_tol, seed):
 @pytest.mark.parametrize("tag,b,t,w,spatial,model_seed,vit_seed,frame_seed", [
     ("P shape, second seed set", 2, 8, 256, "exact", 101, 11, 21),
     ("benched shape T=16 224^2 adaptive", 1, 16, 224, "adaptive", 43, 3, 9),
+    pytest.param("P shape, third seed set", 2, 8, 256, "exact", 57, 5, 33, marks=pytest.mark.slow),
+    pytest.param("benched shape, second seed set", 1, 16, 224, "adaptive", 71, 13, 17, marks=pytest.mark.slow),
 ])      # the two larger of four measured cases (profiles/r3_e2e_seeds.log: 5.4e-6, 3.2e-6, 6.5e-6, 3.0e-6): CPU-oracle time
 def test_end_to_end_mask_mse_over_seeds_and_at_the_benched_shape(tag, b, t, w, spatial, model_seed, vit_seed, frame_seed):
     """the end-to-end gate (frames -> IEEE-half HIP ViT -> 16-bit HIP fusion network vs the all-fp32 oracle
@@ -140,7 +147,7 @@ def test_end_to_end_mask_mse_over_seeds_and_at_the_benched_shape(tag, b, t, w, s
     assert abs(loss.item() - loss_ref.item()) <= 5e-4 * abs(loss_ref.item())
 
 
-@pytest.mark.parametrize("seed", [53])           # the worst of three (ratio 2.03); seeds 7 and 19 in profiles/r3_envelope.log (1.22, 1.19); the suite's wall time is CPU-oracle time
+@pytest.mark.parametrize("seed", [53, pytest.param(7, marks=pytest.mark.slow), pytest.param(19, marks=pytest.mark.slow)])           # the worst of three (ratio 2.03); seeds 7 and 19 in profiles/r3_envelope.log (1.22, 1.19); the suite's wall time is CPU-oracle time
 def test_gradient_envelope_ratio_over_seeds(seed):
     """The gradient gates of test_parity_r2_gpu._grad_report compare the HIP path's distance to the fp32 oracle with the distance of the
     rounding-emulating twin to the same oracle (the envelope).  Both are realisations of one re-routing process, so their RATIO
@@ -165,7 +172,8 @@ def test_gradient_envelope_ratio_over_seeds(seed):
     assert ratio <= 2.5
 
 
-@pytest.mark.parametrize("model_seed,vit_seed,frame_seed", [(101, 11, 21)])      # the worst of four seed sets (5.7e-3); (57, 5, 33): 4.1e-3, (71, 13, 17): 3.0e-3 (profiles/r3_fp8_seeds.log)
+@pytest.mark.parametrize("model_seed,vit_seed,frame_seed", [(101, 11, 21), pytest.param(57, 5, 33, marks=pytest.mark.slow),
+                                                            pytest.param(71, 13, 17, marks=pytest.mark.slow)])      # the worst of four seed sets (5.7e-3); (57, 5, 33): 4.1e-3, (71, 13, 17): 3.0e-3 (profiles/r3_fp8_seeds.log)
 def test_fp8_attention_end_to_end_bound_over_seeds(model_seed, vit_seed, frame_seed):
     """BASELINE config[4] (block-scaled fp8 Q K^T / P V inside the IEEE-half extractor): the end-to-end mask-MSE bound of
     tests/test_parity_r2_gpu.py (1e-2, one seed set: 3.9e-3) on three more seed sets of the P shape."""
