@@ -307,7 +307,9 @@ int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* l
                           int N, int epilogue, int qscale_cols, float qscale, int dtype, void* stream);
 /* weight-stationary GEMM for the same K = 384 layers (attn.qkv, attn.proj, mlp.fc1 of dino's Block; call site
  * video_attention.py:52): C = epilogue(A[M][384] (16-bit, dense rows) . W[N][384]^T), the weights held in registers, the
- * activation rows streamed through LDS in 64-row panels.  epilogue 0 / 1 / 2 as in maavss_vit_gemm.  N % 384 == 0 (one
+ * activation rows streamed through LDS in 64-row panels.  epilogue 0 / 1 / 2 as in maavss_vit_gemm; epilogue 4 (ABI 400, dtype 2
+ * only) = epilogue 1 with the GELU polynomial evaluated in packed IEEE half instead of f32 (mlp.fc1: 7 % faster, twice the
+ * rounding error of the stored value -- VideoAttention(gelu="half"), never the default).  N % 384 == 0 (one
  * workgroup per 384 columns; the N / 384 workgroups of a row range share one XCD's L2), ldc % 8 == 0, qscale_cols % 384 == 0.
  * A and C must be ALLOCATED with a_rows, c_rows >= ceil(M/64)*64 rows (whole panels are read and stored; rows >= M hold
  * don't-care values).  xn_out (epilogue 2 with N = 384 only, may be null): additionally LayerNorm(ln_gamma, ln_beta, ln_eps)

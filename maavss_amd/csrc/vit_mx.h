@@ -8,6 +8,12 @@
 //   sv     [rows_alloc / 32][384]   e8m0, [b][row of v8t]: the scale of the 32 tokens [32 b, 32 b + 32) of that d row: blocks are aligned on the
 //                                   GLOBAL row index (frames are ntok = 785 rows apart, not a multiple of 32), which is why the
 //                                   attention kernel walks a frame's keys in 32-aligned tiles and masks the rows of its neighbours.
+//                                   CONSEQUENCE (documented, tested in tests/test_parity_r4_gpu.py): a block that straddles two frames takes
+//                                   ONE scale from both, so a frame's output depends slightly on its neighbours in the launch group (and
+//                                   on the zero rows after the last frame) -- unlike the 16-bit modes, which are bit-identical per frame.
+//                                   Measured (one frame alone vs inside a group of 8, 224^2): mean map difference 3.3e-3 = 0.44 of the
+//                                   mode's own mean distance to fp32; most of it is the tile ALIGNMENT (a frame's 64-key tiles start at
+//                                   another key, P' is rounded to e4m3 against another running maximum), not the shared scales.
 // rows_alloc = ceil(rows / 128) * 128 + 128: the GEMM stores whole 64-row panels, the attention kernel reads up to 63 rows past
 // a frame's last token (masked; the bytes must only be finite e4m3, the stand-alone quantiser / the caller zero the tail).
 //

@@ -18,7 +18,8 @@
 //   * each wave stores its own [32 x 32] outputs straight from the accumulators (the MFMA row permutation below gives a lane
 //     8 consecutive columns): with three waves per SIMD one wave's epilogue runs under the other two's MFMAs;
 //   * one workgroup barrier per panel.
-// Epilogues: 0 +bias, q-scale -> 16-bit | 1 +bias, GELU -> 16-bit | 2 +bias +residual -> f32 in place, and optionally the
+// Epilogues: 0 +bias, q-scale -> 16-bit | 1 +bias, GELU -> 16-bit (4: the same with the polynomial evaluated in packed IEEE half -- faster, twice
+// the rounding error of the stored value: a selectable mode, vit_epilogue.h) | 2 +bias +residual -> f32 in place, and optionally the
 // NEXT LayerNorm of the updated rows -> 16-bit (ns = 1: the workgroup holds whole rows), so that the consumer GEMM needs no
 // LayerNorm pass | 3 (round 3, attn.qkv only, N = 1152): +bias, q-scale -> the BLOCK-SCALED fp8 operand images of the attention
 // kernel (vit_mx.h) instead of a 16-bit qkv tensor: the q and k slices per (token, 32 columns) -- a wave's 32 output columns are
@@ -26,6 +27,7 @@
 // the operands exchanged (weights as B), so a lane holds one d column and 16 tokens of a 32-token block, quantises per (d, block)
 // and stores 16 consecutive token bytes of a V^T row.  No quantisation pass, 1 byte per element written instead of 2.
 #include <type_traits>
+#include <stdlib.h>
 #include "mma.h"
 #include "vit_epilogue.h"
 #include "vit_mx.h"
@@ -58,8 +60,15 @@ struct WsArgs {
   MxImages mx;           // epi 3
 };
 
-template <int EPI, int LN, int MODE>
+// SH = MFMA shape: 32 = v_mfma_f32_32x32x16 (rounds 2-3; kept for the MX epilogue and as the measured baseline), 16 = v_mfma_f32_16x16x32
+// (round 4, default).  Same FLOPs per cycle on paper; on RANDOM operands the chip is power-limited and holds a higher clock on the
+// 16x16x32 form (scripts/valu_probe part 3: 1612 -> 1868 TFLOP/s, +16 %, register-resident f16 loops; both 2470 on zeros), and a
+// 16x16 accumulator gives a lane 8 consecutive output columns of ONE row with the four lanes of a row adjacent: 64 contiguous
+// bytes per row and store instruction instead of 32.
+template <int EPI, int LN, int MODE, int SH>
 __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
+  static_assert(SH == 32 || SH == 16, "MFMA shape");
+  static_assert(SH == 32 || EPI != 3, "the MX epilogue is built on the 32x32 accumulator layout");
   constexpr bool LN_OUT = LN == 1, LN_IN = LN == 2;
   static_assert(!LN_OUT || EPI == 2, "LayerNorm of the output rows comes with the residual epilogue");
   static_assert(!LN_IN || EPI == 0 || EPI == 3, "LayerNorm on the way in is wired for the attn.qkv epilogues");
@@ -190,12 +199,35 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // ---- stationary weights.  MFMA row i = 8 q + 4 h + r of the A operand is fed with weight row n0 + pi(i),
   // pi(i) = 16 (q >> 1) + 8 h + 4 (q & 1) + r: the accumulator registers (q, r) of a lane (column = activation row, h = lane
   // half) are then the 8 consecutive output columns 16 (q >> 1) + 8 h + (0..7) for q = (0,1) and (2,3).
+  // SH = 16: A-operand block b (16 weight rows) x k-step s (32 deep) = w[12 b + s]; lane (i = lane & 15, G = lane >> 4) holds k = 32 s + 8 G ..
+  // of weight row n0 + col(b, i).  The accumulator of block b gives lane (j, G) the rows 4 G + r, so
+  //   16-bit outputs: col(b, i) = 8 (i >> 2) + 4 b + (i & 3)  ->  the lane's 8 values are the columns 8 G + (0..7): one 16-byte store, and
+  //                   the four lanes G = 0..3 of activation row j cover 64 contiguous bytes;
+  //   f32 outputs:    col(b, i) = 16 b + i                    ->  block b gives the lane columns 16 b + 4 G + (0..3): one float4, the four
+  //                   lanes of a row again 64 contiguous bytes per instruction.
+  // (with the LayerNorm output the 16-bit row wants the 8-consecutive layout: one 16-byte store and 20 instead of 24 vector-memory
+  // operations per panel; measured 429 -> see DESIGN.md; WS16_LN_SPLITCOLS=1 restores the split layout for A/B)
+#ifndef WS16_LN_SPLITCOLS
+#define WS16_LN_SPLITCOLS 0
+#endif
+  constexpr bool F32OUT = EPI == 2 && (LN != 1 || WS16_LN_SPLITCOLS);
+  constexpr int CSTEP = F32OUT ? 16 : 4;              // column distance between the lane's block-0 and block-1 values
+  const int j16 = lane & 15, g16 = lane >> 4;
+  const int cbase16 = F32OUT ? 4 * g16 : 8 * g16;     // first column (within the wave's 32) of the lane's block-0 values
   bf16x8 w[24];
-  {
+  if constexpr (SH == 32) {
     const int q = r32 >> 3, h = (r32 >> 2) & 1, r = r32 & 3;
     const bf16_t* wp = g.W + (int64_t)(n0 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + r) * WS_K + 8 * half;
 #pragma unroll
     for (int kb = 0; kb < 24; ++kb) w[kb] = *reinterpret_cast<const bf16x8*>(wp + kb * 16);
+  } else {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = F32OUT ? 16 * b + j16 : 8 * (j16 >> 2) + 4 * b + (j16 & 3);
+      const bf16_t* wp = g.W + (int64_t)(n0 + col) * WS_K + 8 * g16;
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) w[12 * b + ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
+    }
   }
   if (tid < WS_SLICE) {
     bias_lds[tid] = g.bias[slice * WS_SLICE + tid];
@@ -223,12 +255,15 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // fragment read address: activation row r32 (+ 32 h2), chunk 2 kb + half, kb = 8 a + b:
   //   ((2 b + half) ^ (r32 & 15)) << 4  =  (((b << 5) ^ ((r32 & 14) << 4))) + ((half ^ (r32 & 1)) << 4)
   const int frag_r = r32 * (WS_K * 2) + ((half ^ (r32 & 1)) << 4), frag_x = (r32 & 14) << 4;
+  // SH = 16: activation row 16 c + j16, chunk 4 s + g16:  ((4 s + g16) ^ j16) << 4  =  ((g16 ^ (j16 & 3)) << 4) + (((s & 3) << 6) ^ ((j16 & 12) << 4)) + (s >> 2) * 256
+  const int frag16_r = j16 * (WS_K * 2) + ((g16 ^ (j16 & 3)) << 4), frag16_x = (j16 & 12) << 4;
   const float scale = ((EPI == 0 || EPI == 3) && slice * WS_SLICE < g.qscale_cols) ? g.qscale : 1.f;   // qscale_cols is a multiple of 384
   const bool vslice = EPI == 3 && slice == 2;          // attn.qkv -> MX images: the v slice runs with the MFMA operands exchanged
 
   // vector-memory operations of one panel epilogue (loads + stores) that the hand-counted wait may leave in flight.  EPI 3: a
   // half-panel issues 3 (q, k slices: two 8-byte stores + the scale byte) or 2 (v slice: one 16-byte store + the scale byte)
-  constexpr int S = EPI == 2 ? (LN_OUT ? 20 : 16) : 4;
+  // (SH = 16 with the LayerNorm output: the 16-bit row goes out as two 8-byte pieces per 16-row block instead of one 16-byte piece)
+  constexpr int S = EPI == 2 ? (LN_OUT ? (SH == 16 && WS16_LN_SPLITCOLS ? 24 : 20) : 16) : 4;
   int it = 0;
   for (int p = p0; p < p1; ++p, ++it) {
     const int buf = it & 1;
@@ -249,6 +284,145 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           WS_FETCH_X(2 * (p + 1) + h2, stats_next, srow)
         }
       }
+      if constexpr (SH == 16) {
+        // ================= 16x16x32 form: two 16-row blocks (c) x two 16-column blocks (b) of accumulators =================
+        const char* pb16 = panels_lds + buf * WS_PANEL_BYTES + h2 * (32 * WS_K * 2) + frag16_r;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float4 bq = *reinterpret_cast<const float4*>(bias_lds + wv * 32 + cbase16 + CSTEP * b);
+          acc[0][b] = f32x4{bq.x, bq.y, bq.z, bq.w};
+          acc[1][b] = acc[0][b];
+        }
+        // fragment t = 2 ks + c: rows 16 c .., k-step ks; it feeds the two MFMAs of column blocks b = 0, 1
+        auto rd16 = [&](int t) __attribute__((always_inline)) {
+          int fx = frag16_x;
+          if constexpr (EPI != 1) asm volatile("" : "+v"(fx));
+          const int c = t & 1, ks = t >> 1;
+          return *reinterpret_cast<const bf16x8*>(pb16 + c * (16 * WS_K * 2) + (((ks & 3) << 6) ^ fx) + (ks >> 2) * 256);
+        };
+        constexpr int D16 = LN_IN ? 1 : (EPI == 2) ? 2 : 3;       // fragments in flight ahead of their MFMAs (the variants short of registers: 2)
+        {
+          bf16x8 f[D16 + 1];
+#pragma unroll
+          for (int t = 0; t < D16; ++t) f[t] = rd16(t);
+#pragma unroll
+          for (int t = 0; t < 24; ++t) {
+            if (t + D16 < 24 && !(abl & 8)) f[(t + D16) % (D16 + 1)] = rd16(t + D16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(abl & 4)) {
+              Mma<MODE>::mma(acc[t & 1][0], w[t >> 1], f[t % (D16 + 1)]);
+              Mma<MODE>::mma(acc[t & 1][1], w[12 + (t >> 1)], f[t % (D16 + 1)]);
+            } else if (t == 23) {
+#pragma unroll
+              for (int i = 0; i <= D16; ++i) acc[0][0][0] += (float)f[i][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // ---- epilogue: lane (j16, g16) holds, of rows m0 + 32 h2 + 16 c + j16 (c = 0, 1): 16-bit outputs -- the columns n0 + 8 g16 + (0..7)
+        // = (acc[c][0], acc[c][1]); f32 outputs -- the columns n0 + 16 b + 4 g16 + (0..3) = acc[c][b]
+        const int64_t row0 = m0 + 32 * h2 + j16;
+        bool skip_epi16 = false;
+        if constexpr ((abl & 1) != 0) skip_epi16 = acc[0][0][3] != 1234.5f;
+        if (!skip_epi16) {
+        if constexpr (EPI != 2) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (row0 + 16 * c) * g.ldc + n0 + 8 * g16;
+            v2f v[4] = {v2f{acc[c][0][0], acc[c][0][1]}, v2f{acc[c][0][2], acc[c][0][3]}, v2f{acc[c][1][0], acc[c][1][1]}, v2f{acc[c][1][2], acc[c][1][3]}};
+            if constexpr (EPI == 4) {
+              *reinterpret_cast<uint4*>(cp) = make_uint4(pg_gelu_h2(v[0]), pg_gelu_h2(v[1]), pg_gelu_h2(v[2]), pg_gelu_h2(v[3]));
+              continue;
+            } else if constexpr (EPI == 1) {
+              pg_gelu4(v[0], v[1]);
+              pg_gelu4(v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e].x *= scale; v[e].y *= scale; }     // scalar multiplies on purpose (vit_epilogue.h)
+            }
+            *reinterpret_cast<uint4*>(cp) = make_uint4(pack2<MODE>(v[0].x, v[0].y), pack2<MODE>(v[1].x, v[1].y),
+                                                       pack2<MODE>(v[2].x, v[2].y), pack2<MODE>(v[3].x, v[3].y));
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float* cp = reinterpret_cast<float*>(g.C) + (row0 + 16 * c) * g.ldc + n0 + cbase16;
+            const float4 x0 = *reinterpret_cast<const float4*>(cp), x1 = *reinterpret_cast<const float4*>(cp + CSTEP);
+            acc[c][0][0] += x0.x; acc[c][0][1] += x0.y; acc[c][0][2] += x0.z; acc[c][0][3] += x0.w;     // scalar adds on purpose (vit_epilogue.h)
+            acc[c][1][0] += x1.x; acc[c][1][1] += x1.y; acc[c][1][2] += x1.z; acc[c][1][3] += x1.w;
+            *reinterpret_cast<float4*>(cp) = make_float4(acc[c][0][0], acc[c][0][1], acc[c][0][2], acc[c][0][3]);
+            *reinterpret_cast<float4*>(cp + CSTEP) = make_float4(acc[c][1][0], acc[c][1][1], acc[c][1][2], acc[c][1][3]);
+          }
+          if constexpr (LN_OUT) {
+            // LayerNorm of the updated rows.  Per wave: (mean, M2) of its 32 columns of each of the 32 rows.  A lane holds 8 of them for
+            // row (c = 0, j16) and 8 for row (c = 1, j16); the other 24 are in the lanes j16 + 16 G'.  ONE pair of lane swaps reduces both
+            // rows at once: permlane16_swap on (s0, s1) leaves a + b = (s0_0 + s0_1, s1_0 + s1_1, s0_2 + s0_3, s1_2 + s1_3) by 16-lane row,
+            // permlane32_swap on two copies of that adds rows 0 + 2 and 1 + 3 -> lanes with even G hold row c = 0's total, odd G row c = 1's.
+            auto reduce2 = [&](float s0, float s1) __attribute__((always_inline)) {
+              asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s0), "+v"(s1));
+              float ua, ub;
+              lane_swap32(s0 + s1, ua, ub);
+              return ua + ub;
+            };
+            const int cme = g16 & 1;                              // the row block this lane merges: rows 16 cme + j16
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s0 += acc[0][b][r]; s1 += acc[1][b][r]; }
+            const float mu = reduce2(s0, s1) * (1.f / 32.f);       // wave-level mean of row (cme, j16)
+            float mu0, mu1;
+            lane_swap16(mu, mu0, mu1);                             // rows (v0, v0, v2, v2) / (v1, v1, v3, v3): both rows' means in every lane
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float d0 = acc[0][b][r] - mu0, d1 = acc[1][b][r] - mu1;
+                q0 += d0 * d0;
+                q1 += d1 * d1;
+              }
+            const float m2 = reduce2(q0, q1);
+            // [wave][row] partials (conflict-free: consecutive 8-byte slots per 16-lane group)
+            float2* sp = stat_lds + (32 * h2 + 16 * cme + j16);
+            if (g16 < 2) sp[wv * WS_BM] = make_float2(mu, m2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float mean = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < WS_WAVES; ++k) mean += sp[k * WS_BM].x;
+            mean *= 1.f / WS_WAVES;
+            float tot = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < WS_WAVES; ++k) { const float2 st = sp[k * WS_BM]; const float d = st.x - mean; tot += st.y + 32.f * d * d; }
+            const float rstd = rsqrtf(tot * (1.f / WS_K) + g.ln_eps);
+            float mean_c[2], rstd_c[2];
+            lane_swap16(mean, mean_c[0], mean_c[1]);
+            lane_swap16(rstd, rstd_c[0], rstd_c[1]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              bf16_t* xp = g.XN + (row0 + 16 * c) * WS_K + n0 + cbase16;
+              uint2 o[2];
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const int nl = wv * 32 + cbase16 + CSTEP * b;
+                const float4 gg = *reinterpret_cast<const float4*>(gam_lds + nl), bb = *reinterpret_cast<const float4*>(bet_lds + nl);
+                o[b] = make_uint2(pack2<MODE>((acc[c][b][0] - mean_c[c]) * rstd_c[c] * gg.x + bb.x, (acc[c][b][1] - mean_c[c]) * rstd_c[c] * gg.y + bb.y),
+                                  pack2<MODE>((acc[c][b][2] - mean_c[c]) * rstd_c[c] * gg.z + bb.z, (acc[c][b][3] - mean_c[c]) * rstd_c[c] * gg.w + bb.w));
+              }
+              if constexpr (F32OUT) {
+                *reinterpret_cast<uint2*>(xp) = o[0];
+                *reinterpret_cast<uint2*>(xp + CSTEP) = o[1];
+              } else {
+                *reinterpret_cast<uint4*>(xp) = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+              }
+            }
+          }
+        }
+        }   // skip_epi16 (measurement builds)
+      } else {
+      // ================= 32x32x16 form (rounds 2-3) =================
       const char* pb = panels_lds + buf * WS_PANEL_BYTES + h2 * (32 * WS_K * 2) + frag_r;
       f32x16 acc;
 #pragma unroll
@@ -269,12 +443,12 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
         // six): there the eight fragment addresses are precomputed (registers paid for with one step less of read-ahead).  The
         // other variants have no registers left and recompute the address per read (one v_xad).
         int fx = frag_x;
-        if constexpr (EPI != 1) asm volatile("" : "+v"(fx));
+        asm volatile("" : "+v"(fx));
         return *reinterpret_cast<const bf16x8*>(pb + (((kb & 7) << 5) ^ fx) + (kb >> 3) * 256);
       };
       // fragment reads kept in flight ahead of the MFMA that consumes them (the residual epilogues are HBM-bound and short of
       // registers: one)
-      constexpr int WS_DEPTH = (EPI == 2 || EPI == 3) ? 1 : (LN_IN || EPI == 1) ? 2 : 3;
+      constexpr int WS_DEPTH = (EPI == 2 || EPI == 3) ? 1 : (LN_IN || EPI == 1 || EPI == 4) ? 2 : 3;
       auto mfma_loop = [&](auto swapped_c) __attribute__((always_inline)) {
         constexpr bool SWAPPED = decltype(swapped_c)::value;   // C^T = X W^T: lane = output column, registers = rows (EPI 3, v slice)
         bf16x8 f[WS_DEPTH + 1];
@@ -346,12 +520,15 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           v2f v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v2f{acc[8 * qp + 2 * e], acc[8 * qp + 2 * e + 1]};
-          if constexpr (EPI == 1) {
+          if constexpr (EPI == 4) {
+            *reinterpret_cast<uint4*>(cp + 16 * qp) = make_uint4(pg_gelu_h2(v[0]), pg_gelu_h2(v[1]), pg_gelu_h2(v[2]), pg_gelu_h2(v[3]));
+            continue;
+          } else if constexpr (EPI == 1) {
             pg_gelu4(v[0], v[1]);
             pg_gelu4(v[2], v[3]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * scale;
+            for (int e = 0; e < 4; ++e) { v[e].x *= scale; v[e].y *= scale; }
           }
           *reinterpret_cast<uint4*>(cp + 16 * qp) = make_uint4(pack2<MODE>(v[0].x, v[0].y), pack2<MODE>(v[1].x, v[1].y),
                                                                  pack2<MODE>(v[2].x, v[2].y), pack2<MODE>(v[3].x, v[3].y));
@@ -410,6 +587,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
         }
       }
       }   // skip_epi (measurement builds)
+      }   // SH
       if constexpr (SPLIT) {
         if (more) {
           WS_WAIT_FETCH(S / 2)         // younger than the fetch: this half-panel's S / 2 epilogue operations
@@ -457,13 +635,23 @@ static int ws_gemm_launch(const char* who, const void* A, const float* X, const 
   const size_t smem = WS_BUFS * WS_PANEL_BYTES + 3 * WS_SLICE * sizeof(float) + WS_BM * WS_WAVES * sizeof(float2);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(8 * cu_per_xcd), block(WS_THREADS);
-#define WS_LAUNCH3(E, L, D)                                                                                           \
-  {                                                                                                                   \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_ws_gemm_kernel<E, L, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D>), grid, block, smem, st, g);                                      \
+  // MFMA shape: 16x16x32 unless MAAVSS_WS_SHAPE=32 asks for the round-2/3 form (A/B runs; read once per process); the MX epilogue is 32x32 only
+  static int shape_env = 0;
+  if (!shape_env) {
+    const char* e = getenv("MAAVSS_WS_SHAPE");
+    shape_env = (e && e[0] == '3') ? 32 : 16;
   }
+#define WS_LAUNCH4(E, L, D, H)                                                                                        \
+  {                                                                                                                   \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(vit_ws_gemm_kernel<E, L, D, H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((vit_ws_gemm_kernel<E, L, D, H>), grid, block, smem, st, g);                                   \
+  }
+#define WS_LAUNCH3(E, L, D) { if (shape_env == 32) WS_LAUNCH4(E, L, D, 32) else WS_LAUNCH4(E, L, D, 16) }
 #define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
-  if (X && epilogue == 3) WS_LAUNCH(3, 2) else if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
+  if (X && epilogue == 3) { if (dtype == MODE_F16) WS_LAUNCH4(3, 2, MODE_F16, 32) else WS_LAUNCH4(3, 2, MODE_BF16, 32) }
+  else if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0)
+  else if (epilogue == 4) WS_LAUNCH3(4, 0, MODE_F16) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
+#undef WS_LAUNCH4
 #undef WS_LAUNCH3
 #undef WS_LAUNCH
   MAAVSS_LAUNCH_CHECK("vit_ws_gemm_kernel");
@@ -475,7 +663,8 @@ extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const 
                                   const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream) {
   MAAVSS_CHECK_ARG(A && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm: bad arguments");
   MAAVSS_CHECK_ARG(N % WS_SLICE == 0 && N >= WS_SLICE, "vit_ws_gemm: N must be a multiple of 384 (got %d)", N);
-  MAAVSS_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "vit_ws_gemm: unknown epilogue");
+  MAAVSS_CHECK_ARG((epilogue >= 0 && epilogue <= 2) || epilogue == 4, "vit_ws_gemm: unknown epilogue");
+  MAAVSS_CHECK_ARG(epilogue != 4 || dtype == MODE_F16, "vit_ws_gemm: epilogue 4 (GELU evaluated in packed half) needs the IEEE-half storage format (dtype 2)");
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm: dtype must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(lda == WS_K, "vit_ws_gemm: A must be dense [rows][384] (lda = %d)", lda);
   MAAVSS_CHECK_ARG(a_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm: A needs ceil(M/64)*64 = %ld allocated rows (got %ld): whole panels are read",

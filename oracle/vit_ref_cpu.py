@@ -79,7 +79,7 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
     return torch.cat([pos_embed[:, :1], patch], 1)
 
 
-_ROUND = {"bf16": torch.bfloat16, "f16": torch.float16}
+_ROUND = {"bf16": torch.bfloat16, "f16": torch.float16, "f16-gelu-half": torch.float16}   # the last: VideoAttention(gelu="half")
 
 
 def _rounder(emulate):
@@ -120,6 +120,32 @@ def gelu_poly(v):
     return v * (c * q + 0.5)
 
 
+_GELU_T = (-2.420778323e-01, 4.003976983e-01, -3.264899766e-01, 2.595298127e-01, -2.277023313e-01, 1.849680812e-01,
+           -1.484367893e-01, 1.680398153e-01)
+
+
+def gelu_poly_h2(v):
+    """fc1's GELU as VideoAttention(gelu="half") evaluates it (maavss_amd/csrc/vit_epilogue.h pg_gelu_h2, epilogue 4): the same
+    polynomial re-expanded in t = c^2 / 16 - 0.55, EVERY operation in IEEE half with one rounding (the packed fused multiply-adds
+    are exact up to it: emulated in float64).  Returns f32 holding half-representable values."""
+    hd = torch.float16
+
+    def fma(x, y, z):
+        return (x.double() * y.double() + z.double()).to(hd)
+
+    def const(x, like):
+        return torch.full_like(like, x, dtype=hd)
+    h = v.to(hd)
+    lim = torch.tensor(4.2, dtype=hd)
+    c = torch.minimum(torch.maximum(h, -lim), lim)
+    t = fma((c.double() * 0.0625).to(hd), c, const(-0.55, c))
+    q = fma(t, const(_GELU_T[0], t), const(_GELU_T[1], t))
+    for k in _GELU_T[2:]:
+        q = fma(q, t, const(k, t))
+    r = fma(c, q, const(0.5, c))
+    return (h.double() * r.double()).to(hd).float()
+
+
 def flash_attention_emulated(q, k, v, r):
     """softmax(q k^T) v of the flash kernel, rounding where it rounds: key tiles of 64 in order, a running maximum that
     only moves when a tile exceeds it by more than 2^5 (first tile: rebased to its own maximum), P = exp2(s - m) rounded
@@ -147,8 +173,8 @@ def block_forward(sd, i, x, return_attention=False, emulate=None):
     """One pre-LN block.  `emulate` ("bf16" / "f16") rounds exactly where the HIP kernels store 16-bit values:
     the weights, the LayerNorm output, q (after the log2(e)/8 scale) / k / v, the exponentiated probabilities that enter
     P.V (tile-wise, with the kernel's deferred running maximum; the row sum keeps the unrounded f32 values), the attention
-    output and the GELU output (the kernel's polynomial GELU for fc1); accumulation, biases, residual stream and softmax
-    stay f32.  What is left between this and the kernels is summation order and hardware exp2 / rsqrt ulps."""
+    output and the GELU output (the kernel's polynomial GELU for fc1; emulate="f16-gelu-half": evaluated IN half, gelu_poly_h2);
+    accumulation, biases, residual stream and softmax stay f32.  What is left between this and the kernels is summation order and hardware exp2 / rsqrt ulps."""
     p = f"blocks.{i}."
     b, n, _ = x.shape
     r = _rounder(emulate)
@@ -173,7 +199,7 @@ def block_forward(sd, i, x, return_attention=False, emulate=None):
     x = x + F.linear(y, r(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
     y = r(F.layer_norm(x, (DIM,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS))
     h = F.linear(y, r(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])
-    y = r(gelu_poly(h)) if emulate else F.gelu(h)
+    y = (gelu_poly_h2(h) if emulate == "f16-gelu-half" else r(gelu_poly(h))) if emulate else F.gelu(h)
     return x + F.linear(y, r(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
 
 

@@ -168,6 +168,40 @@ def test_vit_ws_gemm(m, n, dt):
               m, n, 2, 0, 1.0, None, None, None, 1e-6, dt, _st())
 
 
+def test_vit_ws_gemm_gelu_in_packed_half_matches_its_emulation():
+    """Epilogue 4 (VideoAttention(gelu="half")) evaluates fc1's GELU polynomial IN packed half (vit_epilogue.h pg_gelu_h2, round 4).  Against
+    oracle/vit_ref_cpu.gelu_poly_h2 -- the same operations, one rounding each -- on the torch f32 pre-activations: the two differ only
+    where the MFMA's summation order moves a pre-activation across a half rounding boundary (then by the polynomial's sensitivity to one
+    input ulp), so nearly every element is bit-identical; and against the exact-erf GELU within the bound measured in
+    tests/tools/gelu_h2_error.py (max 3.1e-3 on v in [-6, 6]).  Inputs scaled so that |pre-activation| reaches 5 (the clamp at 4.2)."""
+    from oracle import vit_ref_cpu as vref
+    m, n, k, dt = 64 * 40 + 7, 1536, 384, 2
+    a = rd(rnd(m, k, seed=16) * 1.6, dt)
+    w, bias = rd(rnd(n, k, seed=14, scale=k ** -0.5), dt), rnd(n, seed=15, scale=0.3)
+    z = a.float() @ w.float().t() + bias
+    assert z.abs().max().item() > 4.5
+    mp = (m + 63) // 64 * 64
+    ac = torch.zeros(mp, k, dtype=DT[dt], device="cuda")
+    ac[:m] = a.cuda()
+    c = torch.empty(mp, n, dtype=DT[dt], device="cuda")
+    wc, bc = w.cuda(), bias.cuda()
+    _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), bc.data_ptr(), c.data_ptr(), n, mp, m, n, 4, 0, 1.0,
+          None, None, None, 1e-6, dt, _st())
+    got = c[:m].float().cpu()
+    emu = vref.gelu_poly_h2(z)
+    same = (got == emu).float().mean().item()
+    d = (got - emu).abs()
+    exact = F.gelu(z.double()).float()
+    print(f"[gelu h2] bit-identical to the emulation: {same * 100:.2f} % of {got.numel()} elements; max |diff| {d.max().item():.2e}; "
+          f"vs exact-erf GELU: max {(got - exact).abs().max().item():.2e}, rms {(got - exact).pow(2).mean().sqrt().item():.2e}")
+    assert same >= 0.97
+    assert d.max().item() <= 8e-3                       # a flipped input ulp at |v| ~ 4: 2 ulp of the result
+    assert (got - exact).abs().max().item() <= 4e-3     # 3.1e-3 in the simulation + the pre-activation's own summation-order noise
+    with pytest.raises(Exception, match="IEEE-half"):    # bf16 storage has no packed-half form
+        _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), bc.data_ptr(), c.data_ptr(), n, mp, m, n, 4, 0, 1.0,
+              None, None, None, 1e-6, 0, _st())
+
+
 @pytest.mark.parametrize("dt", [0, 2])
 @pytest.mark.parametrize("m,n", [(1000, 1152), (16 * 1025, 768), (64 * 300 + 1, 1152), (130, 384)])
 def test_vit_ws_gemm_with_layernorm_on_the_way_in(m, n, dt):
