@@ -66,8 +66,12 @@ def main(path):
                 in_asm = False
                 txt = "\n".join(block)
                 if "global_load_dwordx" in txt:
+                    # alternative fetch blocks (with / without the row statistics) are laid out one after the other and only one of them
+                    # executes: until the wait, the registers of ALL of them count as pending (round 4: a copy of st2 placed right behind
+                    # the block that loads it went unnoticed because a later alternative had replaced the pending set)
+                    if state != "pending":
+                        pending, span = set(), []
                     state, n_fetch = "pending", n_fetch + 1
-                    pending, span = set(), []
                     for b in block:
                         m = re.match(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", b.strip())
                         if m:

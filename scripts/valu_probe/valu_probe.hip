@@ -16,9 +16,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-enum { I_FMA32, I_PKFMA32, I_PKMUL32, I_PKFMA16, I_PKMUL16, I_PKMAX16, I_MED3, I_EXP32, I_EXP16, I_CVTPK16, I_MAX3, I_ADD32, I_DOT2, I_PKADD16, I_MUL32, I_MAX32, I_FMAC32, I_FMA32_S, I_FMA32_3V, I_PKFMA16_3V, I_PKADD32, I_SUB32, I_MOV, I_MAX32_E64, I_CVTPKBF16, I_XOR, I_FMAAK, I_MUL32_E64, I_PKMUL16_3V, I_LSHL, I_PERM, I_CNDMASK, I_N };
+enum { I_FMA32, I_PKFMA32, I_PKMUL32, I_PKFMA16, I_PKMUL16, I_PKMAX16, I_MED3, I_EXP32, I_EXP16, I_CVTPK16, I_MAX3, I_ADD32, I_DOT2, I_PKADD16, I_MUL32, I_MAX32, I_FMAC32, I_FMA32_S, I_FMA32_3V, I_PKFMA16_3V, I_PKADD32, I_SUB32, I_MOV, I_MAX32_E64, I_CVTPKBF16, I_XOR, I_FMAAK, I_MUL32_E64, I_PKMUL16_3V, I_LSHL, I_PERM, I_CNDMASK, I_MAX3_3V, I_MAX32_2V, I_EXP32_D, I_CVTPK16_2V, I_N };
 static const char* kNames[I_N] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_fma_f16", "v_pk_mul_f16", "v_pk_max_f16", "v_med3_f32",
-                                  "v_exp_f32", "v_exp_f16", "v_cvt_pk_f16_f32", "v_max3_f32", "v_add_f32", "v_dot2c_f32_f16", "v_pk_add_f16", "v_mul_f32", "v_max_f32", "v_fmac_f32", "v_fma_f32(v,s,s)", "v_fma_f32(3 vgpr)", "v_pk_fma_f16(3 vgpr)", "v_pk_add_f32", "v_sub_f32", "v_mov_b32", "v_max_f32_e64", "v_cvt_pk_bf16_f32", "v_xor_b32", "v_fmaak_f32", "v_mul_f32_e64", "v_pk_mul_f16(2 vgpr)", "v_lshlrev_b32", "v_perm_b32", "v_cndmask_b32"};
+                                  "v_exp_f32", "v_exp_f16", "v_cvt_pk_f16_f32", "v_max3_f32", "v_add_f32", "v_dot2c_f32_f16", "v_pk_add_f16", "v_mul_f32", "v_max_f32", "v_fmac_f32", "v_fma_f32(v,s,s)", "v_fma_f32(3 vgpr)", "v_pk_fma_f16(3 vgpr)", "v_pk_add_f32", "v_sub_f32", "v_mov_b32", "v_max_f32_e64", "v_cvt_pk_bf16_f32", "v_xor_b32", "v_fmaak_f32", "v_mul_f32_e64", "v_pk_mul_f16(2 vgpr)", "v_lshlrev_b32", "v_perm_b32", "v_cndmask_b32", "v_max3_f32(3 vgpr)", "v_max_f32(d!=s)", "v_exp_f32(d!=s)", "v_cvt_pk_f16(2 vgpr)"};
 
 template <int I>
 __device__ __forceinline__ void one(float& a, v2f& p, unsigned& h, float c, v2f pc, unsigned hc) {
@@ -53,6 +53,10 @@ __device__ __forceinline__ void one(float& a, v2f& p, unsigned& h, float c, v2f 
   if constexpr (I == I_PKMUL16_3V) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(h) : "v"(hc), "v"(c));
   if constexpr (I == I_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(h));
   if constexpr (I == I_PERM) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(h) : "v"(hc));
+  if constexpr (I == I_MAX3_3V) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "v"(pc.y));
+  if constexpr (I == I_MAX32_2V) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(c), "v"(pc.y));
+  if constexpr (I == I_EXP32_D) asm volatile("v_exp_f32 %0, %1" : "=v"(a) : "v"(c));
+  if constexpr (I == I_CVTPK16_2V) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(c), "v"(pc.y));
   if constexpr (I == I_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(h) : "v"(hc));
 }
 
@@ -225,7 +229,9 @@ int main() {
   run_rate<I_PKFMA32>(d_cyc, d_sink); run_rate<I_PKFMA16>(d_cyc, d_sink); run_rate<I_EXP32>(d_cyc, d_sink); run_rate<I_CVTPK16>(d_cyc, d_sink);
   run_rate<I_MOV>(d_cyc, d_sink); run_rate<I_FMAC32>(d_cyc, d_sink); run_rate<I_MAX3>(d_cyc, d_sink);
   printf("# part 2: {24 dependent v_mfma_f32_32x32x16_f16 ; NV vector instructions} per loop iteration, 12 waves per CU\n");
-    run_mix<I_FMA32, 64>(d_cyc, d_sink); run_mix<I_FMA32_S, 64>(d_cyc, d_sink); run_mix<I_FMA32_3V, 64>(d_cyc, d_sink); run_mix<I_FMAC32, 64>(d_cyc, d_sink);
+    run_mix<I_MAX3, 16>(d_cyc, d_sink); run_mix<I_MAX3_3V, 16>(d_cyc, d_sink); run_mix<I_MAX3_3V, 64>(d_cyc, d_sink); run_mix<I_MAX32_2V, 32>(d_cyc, d_sink); run_mix<I_MAX32_2V, 64>(d_cyc, d_sink);
+  run_mix<I_EXP32_D, 32>(d_cyc, d_sink); run_mix<I_CVTPK16_2V, 16>(d_cyc, d_sink); run_mix<I_ADD32, 32>(d_cyc, d_sink);
+  run_mix<I_FMA32, 64>(d_cyc, d_sink); run_mix<I_FMA32_S, 64>(d_cyc, d_sink); run_mix<I_FMA32_3V, 64>(d_cyc, d_sink); run_mix<I_FMAC32, 64>(d_cyc, d_sink);
   run_mix<I_FMAAK, 64>(d_cyc, d_sink); run_mix<I_MUL32, 64>(d_cyc, d_sink); run_mix<I_MUL32_E64, 64>(d_cyc, d_sink); run_mix<I_ADD32, 64>(d_cyc, d_sink);
   run_mix<I_SUB32, 64>(d_cyc, d_sink); run_mix<I_MAX32, 64>(d_cyc, d_sink); run_mix<I_MAX32_E64, 64>(d_cyc, d_sink); run_mix<I_MAX3, 64>(d_cyc, d_sink);
   run_mix<I_MOV, 64>(d_cyc, d_sink); run_mix<I_XOR, 64>(d_cyc, d_sink); run_mix<I_LSHL, 64>(d_cyc, d_sink); run_mix<I_PERM, 64>(d_cyc, d_sink);

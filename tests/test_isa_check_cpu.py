@@ -63,3 +63,18 @@ def test_wait_that_counts_more_memory_operations_than_were_issued_is_rejected(tm
     straight = HALF_STEPS.replace(".LBB0_2:\n", "").replace("\ts_cbranch_scc0 .LBB0_2\n", "")
     assert run(tmp_path, kernel(steps=straight)) == 1                     # the same two stores, not in a loop: 2 < 4
     assert run(tmp_path, kernel(steps=straight + straight)) == 0          # unrolled: 4
+
+
+def test_copy_behind_a_non_last_alternative_fetch_block_is_rejected(tmp_path):
+    """Round 4: the loop body had three ALTERNATIVE fetch blocks (no statistics / three-part / two-part statistics), laid out one after
+    the other; hipcc placed `v_mov v139, v127` right behind the block that loads v[126:127] -- before the load had landed -- and the
+    check, which only remembered the registers of the LAST fetch block in layout order, let it pass (the parts = 3 GPU test caught it).
+    Until the wait, the registers of every alternative count as pending."""
+    alt_a = FETCH.replace("global_load_dwordx4 v[116:119], v[8:9], off offset:1024",
+                          "global_load_dwordx4 v[116:119], v[8:9], off offset:1024\n\tglobal_load_dwordx2 v[126:127], v[10:11], off offset:16")
+    copy = "\tv_mov_b32_e32 v139, v127\n"
+    both = alt_a + copy + "\ts_cbranch_vccnz .LBB0_9\n" + FETCH + ".LBB0_9:\n"
+    text = ("_Z18vit_ws_gemm_kernelILi0ELi2ELi2ELi16EEv6WsArgs: ; @kernel\n" + FETCH + WAIT0 + "\tds_write_b128 v5, v[112:115]\n.LBB0_1:\n\ts_barrier\n" +
+            both + HALF_STEPS + WAIT + "\tds_write_b128 v5, v[112:115]\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert run(tmp_path, text) == 1
+    assert run(tmp_path, text.replace(copy, "")) == 0
