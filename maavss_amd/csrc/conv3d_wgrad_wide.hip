@@ -21,8 +21,16 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   using E = typename M::elem;
   constexpr int MT = CI / 16, NT = CO / 16, NTAP = KDN * 25, NPAIR = NTAP * MT, PW = (NPAIR + 7) / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  E* xs = reinterpret_cast<E*>(smem);        // [KDN][20 rows][20 cols][CI]
-  E* ds = xs + KDN * 400 * CI;               // [16][16][CO]
+  // LDS images.  f32 mode: channels-last tiles xs [KDN][20 rows][20 cols][CI], ds [16][16][CO] (scalar reads).  16-bit modes (round 4): PLANAR by
+  // 16-channel block -- xs [KDN][CI / 16][400 positions][16], ds [CO / 16][256 positions][16], planes XP / DP elements apart -- so that the
+  // 32 lanes a ds_read_b64_tr_b16 serves together (8 positions x 4 lanes x 8 bytes) read 256 CONTIGUOUS bytes = every bank once.  In the
+  // channels-last image a fragment touched 32 of every 64 (CI, CO = 32) or 128 (CO = 64) bytes and the lane groups G = 0 / 1 sat exactly 256 bytes
+  // apart: 2-way conflicts on every read, 46-60 % of the kernel's LDS cycles (profiles/r3_e_kernel_pmc.json).  The planes are padded by 64 bytes so
+  // that the staging writes of one position's blocks (plane stride = 0 mod 256 otherwise) spread over the banks too.
+  constexpr bool PLANAR = MODE != MODE_F32;
+  constexpr int XP = 400 * 16 + 32, DP = 256 * 16 + 32;
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ds = xs + (PLANAR ? KDN * MT * XP : KDN * 400 * CI);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int G = lane >> 4, l16 = lane & 15;
   constexpr int KDG = 3 / KDN;               // kd groups (blockIdx.x % KDG)
@@ -83,7 +91,13 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
     for (int j = 0; j < NX; ++j) {
       const int i = tid + j * 512;
       if (i < XV) {
-        E* d = xs + (int64_t)i * 4;   // [kdl][pos][CI]: the float4 index is the element index / 4
+        E* d;
+        if constexpr (PLANAR) {
+          const int c4 = (i % (CI / 4)) * 4, pos = (i / (CI / 4)) % 400, kdl = i / ((CI / 4) * 400);
+          d = xs + (kdl * MT + (c4 >> 4)) * XP + pos * 16 + (c4 & 15);
+        } else {
+          d = xs + (int64_t)i * 4;   // [kdl][pos][CI]: the float4 index is the element index / 4
+        }
         d[0] = M::cvt(xr[j].x); d[1] = M::cvt(xr[j].y); d[2] = M::cvt(xr[j].z); d[3] = M::cvt(xr[j].w);
       }
     }
@@ -91,7 +105,13 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
     for (int j = 0; j < ND; ++j) {
       const int i = tid + j * 512;
       if (i < DV) {
-        E* d = ds + (int64_t)i * DVE;   // [pos][CO]
+        E* d;
+        if constexpr (PLANAR) {
+          const int pos = i / (CO / DVE), cv = (i % (CO / DVE)) * DVE;
+          d = ds + (cv >> 4) * DP + pos * 16 + (cv & 15);
+        } else {
+          d = ds + (int64_t)i * DVE;   // [pos][CO]
+        }
         if constexpr (DY16) {
           *reinterpret_cast<float4*>(d) = dr[j];
         } else {
@@ -120,11 +140,13 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
             if (e < 4) fb[j].lo[e] = v; else fb[j].hi[e - 4] = v;
           }
         } else {
+          // MFMA k slot (G, hh, q = l16 >> 2) <-> tile position (row 2 ks + (G >> 1), column 4 (G & 1) + 8 hh + q): any assignment is valid as
+          // long as both operands use it; this one gives the lanes 0-31 of a read (G = 0, 1) eight CONSECUTIVE positions
           bf16x4 h[2];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const int k = 8 * G + 4 * hh + (l16 >> 2);
-            const E* a = ds + ((2 * ks + (k >> 4)) * 16 + (k & 15)) * CO + j * 16 + (l16 & 3) * 4;
+            const int row = 2 * ks + (G >> 1), col = 4 * (G & 1) + 8 * hh + (l16 >> 2);
+            const E* a = ds + j * DP + (row * 16 + col) * 16 + (l16 & 3) * 4;
             h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
           }
           fb[j] = concat4(h[0], h[1]);
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
         if (q < NPAIR) {  // wave-uniform
           const int tap = q / MT, mi = q % MT;
           const int kdl = tap / 25, kh = (tap % 25) / 5, kw = tap % 5;
-          const E* xb = xs + kdl * 400 * CI + mi * 16;
+          const E* xb = PLANAR ? xs + (kdl * MT + mi) * XP : xs + kdl * 400 * CI + mi * 16;
           typename M::frag fa;
           if constexpr (MODE == MODE_F32) {
 #pragma unroll
@@ -149,8 +171,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
             bf16x4 h[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-              const int k = 8 * G + 4 * hh + (l16 >> 2);
-              const E* a = xb + ((2 * ks + (k >> 4) + kh) * 20 + (k & 15) + kw) * CI + (l16 & 3) * 4;
+              const int row = 2 * ks + (G >> 1) + kh, col = 4 * (G & 1) + 8 * hh + (l16 >> 2) + kw;
+              const E* a = xb + (row * 20 + col) * 16 + (l16 & 3) * 4;
               h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
             }
             fa = concat4(h[0], h[1]);
@@ -180,7 +202,8 @@ template <int MODE, int CI, int CO, int KDN, bool DY16 = false, int CIT = CI>
 static void launch_wide(const float* x, const void* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                         int nchunk, hipStream_t st) {
   using E = typename Mma<MODE>::elem;
-  const size_t smem = (KDN * 400 * CI + 256 * CO) * sizeof(E);
+  const size_t smem = MODE == MODE_F32 ? (KDN * 400 * CI + 256 * CO) * sizeof(E)
+                                       : (size_t)(KDN * (CI / 16) * (400 * 16 + 32) + (CO / 16) * (256 * 16 + 32)) * sizeof(E);
   auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN, DY16, CIT>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);

@@ -14,18 +14,98 @@
 // builds its twiddle table once and walks a grid-stride list of frame PAIRS; (3) two real frames share one complex FFT (z = a + i b,
 // A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i): half the butterflies and LDS passes per frame; (4) one Philox
 // block serves two bins (its four normals: re / im of bins f and f + 64) instead of one.  profiles/r3_stft_bench.json.
+// Round 4: the Stockham FFT runs in radix-8 / radix-4 passes (512 = 8.8.8, 256 = 4.4.4.4, 1024 = 8.8.4.4) with the butterflies in registers:
+// three LDS round trips per frame pair instead of nine, 69 LDS instructions per lane instead of 180, ~270 vector instructions instead of ~900
+// (the kernel is bound by its vector work, not by HBM: DESIGN.md); Box-Muller takes its angle through v_sin_f32 / v_cos_f32, whose argument
+// is in revolutions -- exactly the uniform deviate -- instead of sincospif's software range reduction.  profiles/r4_stft_bench.json.
 #define STFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+// forward DFTs (kernel exp(-2 pi i r q / R)) of R points held in registers, in place
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+  const float2 s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = csub(a1, a3);
+  a0 = cadd(s0, s1);
+  a2 = csub(s0, s1);
+  a1 = make_float2(d0.x + d1.y, d0.y - d1.x);      // d0 - i d1
+  a3 = make_float2(d0.x - d1.y, d0.y + d1.x);      // d0 + i d1
+}
+template <int R>
+__device__ __forceinline__ void dft_r(float2 (&a)[R]) {
+  if constexpr (R == 4) {
+    dft4(a[0], a[1], a[2], a[3]);
+  } else {
+    static_assert(R == 8, "radix 4 or 8");
+    float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    constexpr float kS = 0.70710678118654752f;
+    const float2 t1 = make_float2((o1.x + o1.y) * kS, (o1.y - o1.x) * kS);      // o1 (1 - i) / sqrt 2
+    const float2 t2 = make_float2(o2.y, -o2.x);                                 // -i o2
+    const float2 t3 = make_float2((o3.y - o3.x) * kS, -(o3.x + o3.y) * kS);     // o3 (-1 - i) / sqrt 2
+    a[0] = cadd(e0, o0); a[4] = csub(e0, o0);
+    a[1] = cadd(e1, t1); a[5] = csub(e1, t1);
+    a[2] = cadd(e2, t2); a[6] = csub(e2, t2);
+    a[3] = cadd(e3, t3); a[7] = csub(e3, t3);
+  }
+}
+// One radix-R Stockham pass over N points (P = product of the radices of the earlier passes): butterfly i takes in[i + r N / R], multiplies by
+// exp(-2 pi i r k / (R P)), k = i mod P, transforms, and writes out[(i - k) R + k + q P].  tw = the FULL table exp(-2 pi i q / N), q < N.
+template <int N, int R, int P>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int lane) {
+  constexpr int NB = N / R;
+#pragma unroll
+  for (int i0 = 0; i0 < NB; i0 += 64) {
+    const int i = i0 + lane;
+    if (NB < 64 && i >= NB) break;
+    const int k = i & (P - 1);
+    float2 a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = in[i + r * NB];
+    if constexpr (P > 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw[r * k * (N / (R * P))]);
+    }
+    dft_r<R>(a);
+    const int j = (i - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) out[j + q * P] = a[q];
+  }
+}
+// the whole transform; returns the index (0 / 1) of the ping-pong buffer that holds the result
+template <int N>
+__device__ __forceinline__ int fft_forward(float2* b0, float2* b1, const float2* tw, int lane) {
+  if constexpr (N == 512) {
+    fft_pass<512, 8, 1>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<512, 8, 8>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<512, 8, 64>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    return 1;
+  } else if constexpr (N == 256) {
+    fft_pass<256, 4, 1>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 4>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 16>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 64>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    return 0;
+  } else {
+    static_assert(N == 1024, "n_fft 256, 512 or 1024");
+    fft_pass<1024, 8, 1>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<1024, 8, 8>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<1024, 4, 64>(b0, b1, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<1024, 4, 256>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    return 0;
+  }
+}
 template <int NFFT, int STFT_FPB>
 __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
     const float* __restrict__ audio, int64_t audio_stride, int length, const float* __restrict__ window, int hop,
     int n_frames, int n_bins_out, int total_frames, float* __restrict__ y, float* __restrict__ x,
     const float* __restrict__ noise, float sigma, uint64_t seed, float* __restrict__ clip_absmax) {
-  constexpr int LOG2N = NFFT == 256 ? 8 : (NFFT == 512 ? 9 : 10);
   __shared__ float2 buf[2][STFT_FPB][NFFT];
-  __shared__ float2 tw[NFFT / 2];
+  __shared__ float2 tw[NFFT];                    // exp(-2 pi i q / N) for q < N (the radix-8 / radix-4 passes index up to 7 k N / (8 P) < N)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int q = threadIdx.x; q < NFFT / 2; q += blockDim.x) {
+  for (int q = threadIdx.x; q < NFFT; q += blockDim.x) {
     float s, c;
     sincospif(-2.0f * (float)q / (float)NFFT, &s, &c);
     tw[q] = make_float2(c, s);
@@ -50,23 +130,7 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
       buf[0][wv][n] = make_float2(a0[j0] * wn, two_frames ? a1[j1] * wn : 0.f);
     }
     STFT_WAVE_SYNC();
-    int cur = 0;
-#pragma unroll
-    for (int s = 0; s < LOG2N; ++s) {
-      const int p = 1 << s;
-      for (int i = lane; i < NFFT / 2; i += 64) {
-        const int k = i & (p - 1);
-        float2 u0 = buf[cur][wv][i];
-        float2 u1 = buf[cur][wv][i + NFFT / 2];
-        float2 w = tw[k * (NFFT / (2 * p))];
-        float2 v = make_float2(u1.x * w.x - u1.y * w.y, u1.x * w.y + u1.y * w.x);
-        const int j = ((i - k) << 1) + k;
-        buf[cur ^ 1][wv][j] = make_float2(u0.x + v.x, u0.y + v.y);
-        buf[cur ^ 1][wv][j + p] = make_float2(u0.x - v.x, u0.y - v.y);
-      }
-      STFT_WAVE_SYNC();
-      cur ^= 1;
-    }
+    const int cur = fft_forward<NFFT>(&buf[0][wv][0], &buf[1][wv][0], tw, lane);
     // ---- separate the two spectra and write them (+ the noisy copies); `fr` = 0 / 1 selects the frame of the pair
 #pragma unroll
     for (int fr = 0; fr < 2; ++fr) {
