@@ -65,6 +65,19 @@ struct WsArgs {
 // 16x16x32 form (scripts/valu_probe part 3: 1612 -> 1868 TFLOP/s, +16 %, register-resident f16 loops; both 2470 on zeros), and a
 // 16x16 accumulator gives a lane 8 consecutive output columns of ONE row with the four lanes of a row adjacent: 64 contiguous
 // bytes per row and store instruction instead of 32.
+#ifdef WS_STAMP
+// measurement build (scripts/ws_stamp.py; never loaded by the package): where a wave's cycles go, per phase, summed over its panels
+__device__ unsigned long long ws_stamps[256 * WS_WAVES * 8];
+extern "C" int maavss_ws_stamps_read(unsigned long long* host, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_stamps), sizeof(ws_stamps)) != hipSuccess) return 1;
+  if (clear) { static unsigned long long z[256 * WS_WAVES * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#define WS_T(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
+#else
+#define WS_T(i)
+#endif
+
 template <int EPI, int LN, int MODE, int SH>
 __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   static_assert(SH == 32 || SH == 16, "MFMA shape");
@@ -265,10 +278,14 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // (SH = 16 with the LayerNorm output: the 16-bit row goes out as two 8-byte pieces per 16-row block instead of one 16-byte piece)
   constexpr int S = EPI == 2 ? (LN_OUT ? (SH == 16 && WS16_LN_SPLITCOLS ? 24 : 20) : 16) : 4;
   int it = 0;
+#ifdef WS_STAMP
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int p = p0; p < p1; ++p, ++it) {
     const int buf = it & 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(abl & 16)) __builtin_amdgcn_s_barrier();      // panel p is in LDS for everybody; everybody is done reading panel p-1
+    WS_T(0)                                             // [0] waiting at the panel barrier
     const bool more = p + 1 < p1 && !((abl & 2) && it > 0);
     if constexpr (!SPLIT && !LN_IN) { if (more) WS_FETCH(p + 1) }   // in flight during this panel's MFMAs, written to the other buffer at the end
     const int m0 = p * WS_BM;
@@ -320,6 +337,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        WS_T(1)                                         // [1] bias init + fragment reads + 48 MFMAs
         // ---- epilogue: lane (j16, g16) holds, of rows m0 + 32 h2 + 16 c + j16 (c = 0, 1): 16-bit outputs -- the columns n0 + 8 g16 + (0..7)
         // = (acc[c][0], acc[c][1]); f32 outputs -- the columns n0 + 16 b + 4 g16 + (0..3) = acc[c][b]
         const int64_t row0 = m0 + 32 * h2 + j16;
@@ -588,6 +606,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
       }
       }   // skip_epi (measurement builds)
       }   // SH
+      WS_T(2)                                           // [2] epilogue (arithmetic + issue of its stores)
       if constexpr (SPLIT) {
         if (more) {
           WS_WAIT_FETCH(S / 2)         // younger than the fetch: this half-panel's S / 2 epilogue operations
@@ -597,18 +616,29 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
       if constexpr (LN_IN) {
         if (more) {
           WS_WAIT_FETCH(S / 2)
+          WS_T(3)                      // [3] waiting for the fetched panel (+ the acknowledgement of older stores)
           WS_DEPOSIT_LN(buf ^ 1, table_lds + ((it + 1) % 3) * WS_BM, h2)
           if (stats_next && wv == 0) table_lds[((it + 2) % 3) * WS_BM + lane] = merge_stats(st01, st2);
+          WS_T(4)                      // [4] deposit (LayerNorm arithmetic + LDS writes)
         }
       }
     }
     if constexpr (!SPLIT && !LN_IN) {
       if (more) {
         WS_WAIT_FETCH(S)               // younger than the fetch: exactly this panel's S epilogue operations
+        WS_T(3)
         WS_DEPOSIT(buf ^ 1)            // the buffer panel p-1 left at this iteration's barrier
+        WS_T(4)
       }
     }
   }
+#ifdef WS_STAMP
+  if (lane == 0) {
+    unsigned long long* o = ws_stamps + ((size_t)blockIdx.x * WS_WAVES + wv) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
+    o[5] = (unsigned long long)(p1 - p0);
+  }
+#endif
 }
 
 static int ws_gemm_launch(const char* who, const void* A, const float* X, const float* row_stats, const void* W, const float* bias,
