@@ -31,7 +31,8 @@ extern "C" {
  *   300  round 3: maavss_vit_attn_fp8{,_ws_bytes} removed (-> maavss_vit_attn_mx*); maavss_conv3d_c1_fwd(precise = 2) writes one
  *        stat_partials row per 8-tile workgroup (maavss_conv3d_c1_fwd_nparts), not one per tile; the Philox counter layout of
  *        maavss_stft_fwd's in-kernel noise changed (same seed, different noise)
- *   400  round 4: maavss_set_deterministic_workspace takes the stream the scratch is bound to; see INTEGRATION.md */
+ *   400  round 4: maavss_set_deterministic_workspace takes the stream the scratch is bound to; NULL ln_gamma / ln_beta = LayerNorm without
+ *        the affine part; epilogue 4 of maavss_vit_ws_gemm (GELU in packed half); see INTEGRATION.md */
 #define MAAVSS_ABI_VERSION 400
 const char* maavss_last_error(void);
 int maavss_version(void);
@@ -313,7 +314,11 @@ int maavss_vit_panel_gemm(const float* X, const void* A, int lda, const float* l
  * workgroup per 384 columns; the N / 384 workgroups of a row range share one XCD's L2), ldc % 8 == 0, qscale_cols % 384 == 0.
  * A and C must be ALLOCATED with a_rows, c_rows >= ceil(M/64)*64 rows (whole panels are read and stored; rows >= M hold
  * don't-care values).  xn_out (epilogue 2 with N = 384 only, may be null): additionally LayerNorm(ln_gamma, ln_beta, ln_eps)
- * of every updated row of C -> 16-bit [c_rows][384], so that the consumer GEMM needs no LayerNorm pass. */
+ * of every updated row of C -> 16-bit [c_rows][384], so that the consumer GEMM needs no LayerNorm pass.  ln_gamma = ln_beta = NULL
+ * (ABI 400; here and in maavss_vit_ws_gemm_ln / _ln_mx): the LayerNorm WITHOUT its affine part, (x - mean) * rstd -- for callers that
+ * have folded gamma / beta into the consumer's frozen weights (W' = W diag(gamma), b' = b + W beta).  maavss_amd.VideoAttention does NOT fold by
+ * default: measured +0.3 % clips/s for another rounding realisation of the weights (end-to-end mask-MSE 4.0e-6 ... 8.4e-6 instead of 5.4e-6 ...
+ * 6.5e-6 over the three gated cases: same mean, thinner worst-case margin to 1e-5; HISTORY.md H4). */
 int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, const float* bias, void* C, int ldc,
                        int64_t c_rows, int64_t M, int N, int epilogue, int qscale_cols, float qscale, void* xn_out,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, int dtype, void* stream);

@@ -82,7 +82,12 @@ template <int EPI, int LN, int MODE, int SH>
 __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   static_assert(SH == 32 || SH == 16, "MFMA shape");
   static_assert(SH == 32 || EPI != 3, "the MX epilogue is built on the 32x32 accumulator layout");
-  constexpr bool LN_OUT = LN == 1, LN_IN = LN == 2;
+  // LN: 0 none | 1 LayerNorm of the output rows (proj -> norm2) | 2 LayerNorm of the input rows on the way in (norm1 -> qkv) | 3 / 4 = 1 / 2 WITHOUT
+  // the affine part (ln_gamma = ln_beta = null: plain (x - mean) * rstd), for callers that fold gamma into the consumer GEMM's frozen weight columns
+  // and beta into its bias (W' = W diag(gamma), b' = b + W beta): the deposit of norm1-on-the-way-in then costs two vector instructions per element
+  // instead of three and no gamma / beta reads from LDS.  Measured in the step: +0.3 % (HISTORY.md H4) -- VideoAttention does not fold by default.
+  constexpr bool LN_OUT = LN == 1 || LN == 3, LN_IN = LN == 2 || LN == 4, AFF = LN == 1 || LN == 2;
+  static_assert(LN >= 0 && LN <= 4, "LN variant");
   static_assert(!LN_OUT || EPI == 2, "LayerNorm of the output rows comes with the residual epilogue");
   static_assert(!LN_IN || EPI == 0 || EPI == 3, "LayerNorm on the way in is wired for the attn.qkv epilogues");
   static_assert(EPI != 3 || LN_IN, "the MX epilogue is wired for attn.qkv (LayerNorm on the way in)");
@@ -192,10 +197,15 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   auto deposit_ln_one = [&](char* dst, const float2* tab, int part, int i, const u32x4& raw, int ln) __attribute__((always_inline)) {
     const int q = (wv * 4 + i) * 64 + ln, r = q / 96, c4 = q - r * 96, rr = 32 * part + r;
     const float2 ms = tab[rr];
-    const float4 gg = *reinterpret_cast<const float4*>(gam_lds + 4 * c4), bb = *reinterpret_cast<const float4*>(bet_lds + 4 * c4);
     const float4 v = __builtin_bit_cast(float4, raw);
-    const uint2 o = make_uint2(pack2<MODE>((v.x - ms.x) * ms.y * gg.x + bb.x, (v.y - ms.x) * ms.y * gg.y + bb.y),
-                               pack2<MODE>((v.z - ms.x) * ms.y * gg.z + bb.z, (v.w - ms.x) * ms.y * gg.w + bb.w));
+    uint2 o;
+    if constexpr (AFF) {
+      const float4 gg = *reinterpret_cast<const float4*>(gam_lds + 4 * c4), bb = *reinterpret_cast<const float4*>(bet_lds + 4 * c4);
+      o = make_uint2(pack2<MODE>((v.x - ms.x) * ms.y * gg.x + bb.x, (v.y - ms.x) * ms.y * gg.y + bb.y),
+                     pack2<MODE>((v.z - ms.x) * ms.y * gg.z + bb.z, (v.w - ms.x) * ms.y * gg.w + bb.w));
+    } else {
+      o = make_uint2(pack2<MODE>((v.x - ms.x) * ms.y, (v.y - ms.x) * ms.y), pack2<MODE>((v.z - ms.x) * ms.y, (v.w - ms.x) * ms.y));
+    }
     *reinterpret_cast<uint2*>(dst + rr * (WS_K * 2) + (((c4 >> 1) ^ (rr & 15)) << 4) + (c4 & 1) * 8) = o;
   };
 #define WS_DEPOSIT_LN(buf, tab, part)                                                                             \
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
 #ifndef WS16_LN_SPLITCOLS
 #define WS16_LN_SPLITCOLS 0
 #endif
-  constexpr bool F32OUT = EPI == 2 && (LN != 1 || WS16_LN_SPLITCOLS);
+  constexpr bool F32OUT = EPI == 2 && (!LN_OUT || WS16_LN_SPLITCOLS);
   constexpr int CSTEP = F32OUT ? 16 : 4;              // column distance between the lane's block-0 and block-1 values
   const int j16 = lane & 15, g16 = lane >> 4;
   const int cbase16 = F32OUT ? 4 * g16 : 8 * g16;     // first column (within the wave's 32) of the lane's block-0 values
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   }
   if (tid < WS_SLICE) {
     bias_lds[tid] = g.bias[slice * WS_SLICE + tid];
-    if constexpr (LN != 0) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
+    if constexpr (AFF) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
   }
   if constexpr (!LN_IN) {
     WS_WAIT_FETCH(0)
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           const int c = t & 1, ks = t >> 1;
           return *reinterpret_cast<const bf16x8*>(pb16 + c * (16 * WS_K * 2) + (((ks & 3) << 6) ^ fx) + (ks >> 2) * 256);
         };
-        constexpr int D16 = LN_IN ? 1 : (EPI == 2) ? 2 : 3;       // fragments in flight ahead of their MFMAs (the variants short of registers: 2)
+        constexpr int D16 = LN == 4 ? 2 : LN_IN ? 1 : (EPI == 2) ? 2 : 3;       // fragments in flight ahead of their MFMAs (the variants short of registers: 2)
         {
           bf16x8 f[D16 + 1];
 #pragma unroll
@@ -425,9 +435,14 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
 #pragma unroll
               for (int b = 0; b < 2; ++b) {
                 const int nl = wv * 32 + cbase16 + CSTEP * b;
-                const float4 gg = *reinterpret_cast<const float4*>(gam_lds + nl), bb = *reinterpret_cast<const float4*>(bet_lds + nl);
-                o[b] = make_uint2(pack2<MODE>((acc[c][b][0] - mean_c[c]) * rstd_c[c] * gg.x + bb.x, (acc[c][b][1] - mean_c[c]) * rstd_c[c] * gg.y + bb.y),
-                                  pack2<MODE>((acc[c][b][2] - mean_c[c]) * rstd_c[c] * gg.z + bb.z, (acc[c][b][3] - mean_c[c]) * rstd_c[c] * gg.w + bb.w));
+                if constexpr (AFF) {
+                  const float4 gg = *reinterpret_cast<const float4*>(gam_lds + nl), bb = *reinterpret_cast<const float4*>(bet_lds + nl);
+                  o[b] = make_uint2(pack2<MODE>((acc[c][b][0] - mean_c[c]) * rstd_c[c] * gg.x + bb.x, (acc[c][b][1] - mean_c[c]) * rstd_c[c] * gg.y + bb.y),
+                                    pack2<MODE>((acc[c][b][2] - mean_c[c]) * rstd_c[c] * gg.z + bb.z, (acc[c][b][3] - mean_c[c]) * rstd_c[c] * gg.w + bb.w));
+                } else {
+                  o[b] = make_uint2(pack2<MODE>((acc[c][b][0] - mean_c[c]) * rstd_c[c], (acc[c][b][1] - mean_c[c]) * rstd_c[c]),
+                                    pack2<MODE>((acc[c][b][2] - mean_c[c]) * rstd_c[c], (acc[c][b][3] - mean_c[c]) * rstd_c[c]));
+                }
               }
               if constexpr (F32OUT) {
                 *reinterpret_cast<uint2*>(xp) = o[0];
@@ -596,7 +611,8 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
             unsigned o[4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const float4 gg = *reinterpret_cast<const float4*>(gam_lds + nl + 4 * e), bb = *reinterpret_cast<const float4*>(bet_lds + nl + 4 * e);
+              float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+              if constexpr (AFF) { gg = *reinterpret_cast<const float4*>(gam_lds + nl + 4 * e); bb = *reinterpret_cast<const float4*>(bet_lds + nl + 4 * e); }
               o[2 * e] = pack2<MODE>((acc[8 * qp + 4 * e + 0] - mean) * rstd * gg.x + bb.x, (acc[8 * qp + 4 * e + 1] - mean) * rstd * gg.y + bb.y);
               o[2 * e + 1] = pack2<MODE>((acc[8 * qp + 4 * e + 2] - mean) * rstd * gg.z + bb.z, (acc[8 * qp + 4 * e + 3] - mean) * rstd * gg.w + bb.w);
             }
@@ -678,9 +694,13 @@ static int ws_gemm_launch(const char* who, const void* A, const float* X, const 
   }
 #define WS_LAUNCH3(E, L, D) { if (shape_env == 32) WS_LAUNCH4(E, L, D, 32) else WS_LAUNCH4(E, L, D, 16) }
 #define WS_LAUNCH(E, L) { if (dtype == MODE_F16) WS_LAUNCH3(E, L, MODE_F16) else WS_LAUNCH3(E, L, MODE_BF16) }
-  if (X && epilogue == 3) { if (dtype == MODE_F16) WS_LAUNCH4(3, 2, MODE_F16, 32) else WS_LAUNCH4(3, 2, MODE_BF16, 32) }
-  else if (X) WS_LAUNCH(0, 2) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0)
-  else if (epilogue == 4) WS_LAUNCH3(4, 0, MODE_F16) else if (xn_out) WS_LAUNCH(2, 1) else WS_LAUNCH(2, 0)
+  const bool affine = ln_gamma != nullptr;          // null gamma / beta: the LayerNorm variants without the affine part (folded into the consumer's weights)
+  if (X && epilogue == 3) {
+    if (affine) { if (dtype == MODE_F16) WS_LAUNCH4(3, 2, MODE_F16, 32) else WS_LAUNCH4(3, 2, MODE_BF16, 32) }
+    else { if (dtype == MODE_F16) WS_LAUNCH4(3, 4, MODE_F16, 32) else WS_LAUNCH4(3, 4, MODE_BF16, 32) }
+  }
+  else if (X && affine) WS_LAUNCH(0, 2) else if (X) WS_LAUNCH(0, 4) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0)
+  else if (epilogue == 4) WS_LAUNCH3(4, 0, MODE_F16) else if (xn_out && affine) WS_LAUNCH(2, 1) else if (xn_out) WS_LAUNCH(2, 3) else WS_LAUNCH(2, 0)
 #undef WS_LAUNCH4
 #undef WS_LAUNCH3
 #undef WS_LAUNCH
@@ -702,8 +722,8 @@ extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const 
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm: ldc must be a multiple of 8, qscale_cols a multiple of 384");
   MAAVSS_CHECK_ARG(c_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm: C needs ceil(M/64)*64 = %ld allocated rows (got %ld): stores are unguarded",
                    (long)cdiv(M, WS_BM) * WS_BM, (long)c_rows);
-  MAAVSS_CHECK_ARG(!xn_out || (epilogue == 2 && N == WS_SLICE && ln_gamma && ln_beta),
-                   "vit_ws_gemm: the LayerNorm output needs epilogue 2, N = 384 and the LayerNorm parameters");
+  MAAVSS_CHECK_ARG(!xn_out || (epilogue == 2 && N == WS_SLICE && ((ln_gamma != nullptr) == (ln_beta != nullptr))),
+                   "vit_ws_gemm: the LayerNorm output needs epilogue 2, N = 384 and ln_gamma / ln_beta both given or both null (null = no affine part)");
   return ws_gemm_launch("vit_ws_gemm", A, nullptr, nullptr, W, bias, C, ldc, M, N, epilogue, qscale_cols, qscale, xn_out, ln_gamma, ln_beta,
                         ln_eps, dtype, stream);
 }
@@ -711,7 +731,8 @@ extern "C" int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const 
 extern "C" int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
                                      float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N,
                                      int qscale_cols, float qscale, int dtype, void* stream) {
-  MAAVSS_CHECK_ARG(X && row_stats && ln_gamma && ln_beta && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln: bad arguments");
+  MAAVSS_CHECK_ARG(X && row_stats && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln: bad arguments");
+  MAAVSS_CHECK_ARG((ln_gamma != nullptr) == (ln_beta != nullptr), "vit_ws_gemm_ln: ln_gamma / ln_beta both given or both null (null = no affine part)");
   MAAVSS_CHECK_ARG(N % WS_SLICE == 0 && N >= WS_SLICE, "vit_ws_gemm_ln: N must be a multiple of 384 (got %d)", N);
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm_ln: dtype must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM && c_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM,
@@ -727,7 +748,8 @@ extern "C" int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float
 extern "C" int maavss_vit_ws_gemm_ln_mx(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
                                         float ln_eps, const void* W, const float* bias, void* mx_ws, int64_t M, int qscale_cols, float qscale,
                                         int dtype, void* stream) {
-  MAAVSS_CHECK_ARG(X && row_stats && ln_gamma && ln_beta && W && bias && mx_ws && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln_mx: bad arguments");
+  MAAVSS_CHECK_ARG(X && row_stats && W && bias && mx_ws && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln_mx: bad arguments");
+  MAAVSS_CHECK_ARG((ln_gamma != nullptr) == (ln_beta != nullptr), "vit_ws_gemm_ln_mx: ln_gamma / ln_beta both given or both null (null = no affine part)");
   MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm_ln_mx: dtype (of the weights) must be 0 (bf16) or 2 (f16)");
   MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM, "vit_ws_gemm_ln_mx: X needs ceil(M/64)*64 = %ld allocated rows (got %ld): whole panels are read",
                    (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows);

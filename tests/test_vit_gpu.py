@@ -163,6 +163,11 @@ def test_vit_ws_gemm(m, n, dt):
               xn.data_ptr(), gc.data_ptr(), bc.data_ptr(), 1e-6, dt, _st())
         np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=3e-4)
         np.testing.assert_allclose(xn[:m].float().cpu().numpy(), F.layer_norm(res + z, (k,), gam, bet, 1e-6).numpy(), rtol=8e-3, atol=8e-3)
+        rc[:m] = res.cuda()                 # NULL gamma / beta: the plain normalised rows
+        _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, mp, m, n, 2, 0, 1.0,
+              xn.data_ptr(), None, None, 1e-6, dt, _st())
+        np.testing.assert_allclose(rc[:m].cpu().numpy(), (res + z).numpy(), rtol=1e-4, atol=3e-4)
+        np.testing.assert_allclose(xn[:m].float().cpu().numpy(), F.layer_norm(res + z, (k,), None, None, 1e-6).numpy(), rtol=8e-3, atol=8e-3)
     with pytest.raises(Exception):                     # unpadded buffers are refused
         _call("maavss_vit_ws_gemm", ac.data_ptr(), k, mp, wc.data_ptr(), biasc.data_ptr(), rc.data_ptr(), n, m - 1 if m % 64 == 0 else m,
               m, n, 2, 0, 1.0, None, None, None, 1e-6, dt, _st())
@@ -234,6 +239,28 @@ def test_vit_ws_gemm_with_layernorm_on_the_way_in(m, n, dt):
     _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), gc.data_ptr(), bc.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
           c.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
     np.testing.assert_allclose(c[:m].float().cpu().numpy(), want.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    # NULL gamma / beta = the LayerNorm without its affine part (round 4: VideoAttention folds gamma / beta into the frozen weights): bit-identical
+    # to gamma = 1, beta = 0, and with the folded weights W diag(gamma), b + W beta the same result as above up to the two roundings' order
+    ones, zeros = torch.ones(k, device="cuda"), torch.zeros(k, device="cuda")
+    c1, c0 = torch.empty_like(c), torch.empty_like(c)
+    _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), ones.data_ptr(), zeros.data_ptr(), 1e-6, wc.data_ptr(), biasc.data_ptr(),
+          c1.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), None, None, 1e-6, wc.data_ptr(), biasc.data_ptr(),
+          c0.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    assert torch.equal(c0[:m], c1[:m])
+    wf = rd((w.double() * gam.double()[None, :]).float(), dt)
+    bf_ = (bias.double() + w.double() @ bet.double()).float()
+    wfc, bfc = wf.cuda(), bf_.cuda()
+    _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), None, None, 1e-6, wfc.data_ptr(), bfc.data_ptr(),
+          c0.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    xhat = rd(F.layer_norm(x, (k,), None, None, 1e-6), dt).float()
+    want_f = xhat @ wf.float().t() + bf_
+    want_f[:, :384] *= 0.125
+    np.testing.assert_allclose(c0[:m].float().cpu().numpy(), want_f.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    np.testing.assert_allclose(c0[:m].float().cpu().numpy(), want.numpy(), rtol=3e-2, atol=3e-2)
+    with pytest.raises(Exception, match="both given or both null"):
+        _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), gc.data_ptr(), None, 1e-6, wc.data_ptr(), biasc.data_ptr(),
+              c0.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
 
 
 def test_vit_layernorm_and_patchify():
