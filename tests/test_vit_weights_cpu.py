@@ -50,3 +50,20 @@ def test_missing_file_keeps_seeded_init_and_resize_is_ignored(capsys):
     va = maavss_amd.VideoAttention(path_to_weights="/nonexistent/dino.pth", resize=(112, 112), device="cpu")
     assert va.model.loaded_from is None and va.resize == (112, 112)
     assert "not found" in capsys.readouterr().err          # a notice, on stderr: bench.py's stdout is exactly one JSON line
+
+
+def test_video_attention_mode_arguments_are_validated_on_the_host():
+    """Round 4 options of the drop-in extractor (none of them in the reference's signature): the block-range hybrid of the fp8 attention and
+    the packed-half GELU.  Construction touches no device."""
+    import pytest
+    from maavss_amd.video_attention import DEPTH, VideoAttention
+    kw = dict(path_to_weights="/nonexistent.pth")
+    assert VideoAttention(**kw).fp8_blocks == frozenset() and VideoAttention(**kw).gelu_epilogue == 1
+    assert VideoAttention(attn_dtype="fp8", **kw).fp8_blocks == frozenset(range(DEPTH - 1))
+    assert VideoAttention(attn_dtype="fp8-late", **kw).fp8_blocks == frozenset((8, 9, 10))
+    assert VideoAttention(attn_dtype="fp8", fp8_blocks=(9, 10), **kw).fp8_blocks == frozenset((9, 10))
+    assert VideoAttention(gelu="half", **kw).gelu_epilogue == 4
+    for bad in (dict(attn_dtype="fp4"), dict(fp8_blocks=(3,)), dict(attn_dtype="fp8", fp8_blocks=(11,)), dict(gelu="half", act_dtype="bf16"),
+                dict(gelu="tanh"), dict(act_dtype="fp32"), dict(patch_size=16)):
+        with pytest.raises(ValueError):
+            VideoAttention(**kw, **bad)
