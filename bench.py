@@ -439,7 +439,7 @@ def main():
             stage_row("maavss_stft_fwd", bytes_=per * summ["maavss_stft_fwd"]["calls"])
             if "stft_fwd" in stages:
                 stages["stft_fwd"]["note"] = ("one launch per step over B*T_a frames: at B=32 that is ~2k waves = one wave round of the chip "
-                                              "(launch/latency-bound); the kernel reaches 2.37 TB/s (0.30 of 8 TB/s) at B=256 and 2.5 TB/s at B=8192 "
+                                              "(launch/latency-bound); the kernel reaches 3.10 TB/s (0.39 of 8 TB/s) at B=256 and 2.9 TB/s at B=8192 "
                                               "(profiles/r4_stft_bench.json; round 3: 1.7 / 2.0): one wave per frame pair is bound by its Philox + FFT vector work, not by HBM")
         if "maavss_adam_step" in summ:     # p, g, m, v read + p, m, v written: 28 B per parameter
             stage_row("maavss_adam_step", bytes_=sum(28.0 * a[4] for a in summ["maavss_adam_step"]["args"]))

@@ -32,7 +32,8 @@ extern "C" {
  *        stat_partials row per 8-tile workgroup (maavss_conv3d_c1_fwd_nparts), not one per tile; the Philox counter layout of
  *        maavss_stft_fwd's in-kernel noise changed (same seed, different noise)
  *   400  round 4: maavss_set_deterministic_workspace takes the stream the scratch is bound to; NULL ln_gamma / ln_beta = LayerNorm without
- *        the affine part; epilogue 4 of maavss_vit_ws_gemm (GELU in packed half); see INTEGRATION.md */
+ *        the affine part; epilogue 4 of maavss_vit_ws_gemm (GELU in packed half); the in-kernel noise of maavss_stft_fwd draws the bin n_fft / 2
+ *        from its own per-frame-pair Philox block (same seed, different noise in that bin); see INTEGRATION.md */
 #define MAAVSS_ABI_VERSION 400
 const char* maavss_last_error(void);
 int maavss_version(void);

@@ -163,11 +163,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011) -> 4 x N(0,1) via Box-Muller.
+__device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t k) {
+  uint64_t p;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(a), "s"(k) : "vcc");
+  return p;
+}
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: integer multiplies are quarter rate
+    const uint64_t p0 = mul_wide_u32(c[0], 0xD2511F53u), p1 = mul_wide_u32(c[2], 0xCD9E8D57u);
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -180,7 +186,7 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t idx, floa
   for (int p = 0; p < 2; ++p) {
     float u1 = ((float)(c[2 * p] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(c[2 * p + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float r = sqrtf(-2.0f * __logf(u1));
+    float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));      // v_sqrt_f32 (1 ulp) instead of sqrtf's correctly rounded sequence: noise-grade
     // v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS: sin(2 pi u2) is one instruction each (sincospif: a software range reduction
     // + two polynomials per deviate pair -- a third of this kernel's vector work before round 4); |error| ~1e-6, noise-grade
     out[2 * p] = r * __builtin_amdgcn_cosf(u2);

@@ -53,8 +53,10 @@ __device__ __forceinline__ void dft_r(float2 (&a)[R]) {
 }
 // One radix-R Stockham pass over N points (P = product of the radices of the earlier passes): butterfly i takes in[i + r N / R], multiplies by
 // exp(-2 pi i r k / (R P)), k = i mod P, transforms, and writes out[(i - k) R + k + q P].  tw = the FULL table exp(-2 pi i q / N), q < N.
+// When a pass is ONE butterfly per lane (N / R = 64) `out` may be `in`: the wave's reads are all issued before its first write and the LDS
+// serves one wave's operations in issue order.
 template <int N, int R, int P>
-__device__ __forceinline__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int lane) {
+__device__ __forceinline__ void fft_pass(const float2* in, float2* out, const float2* __restrict__ tw, int lane) {
   constexpr int NB = N / R;
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += 64) {
@@ -74,19 +76,20 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ in, float2* 
     for (int q = 0; q < R; ++q) out[j + q * P] = a[q];
   }
 }
-// the whole transform; returns the index (0 / 1) of the ping-pong buffer that holds the result
+// the whole transform.  512 and 256 points: every pass is one butterfly per lane -> IN PLACE in b0 (b1 unused: half the LDS, twice the
+// workgroups per CU); 1024 points ping-pongs.  Returns the index (0 / 1) of the buffer that holds the result.
 template <int N>
 __device__ __forceinline__ int fft_forward(float2* b0, float2* b1, const float2* tw, int lane) {
   if constexpr (N == 512) {
-    fft_pass<512, 8, 1>(b0, b1, tw, lane); STFT_WAVE_SYNC();
-    fft_pass<512, 8, 8>(b1, b0, tw, lane); STFT_WAVE_SYNC();
-    fft_pass<512, 8, 64>(b0, b1, tw, lane); STFT_WAVE_SYNC();
-    return 1;
+    fft_pass<512, 8, 1>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<512, 8, 8>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<512, 8, 64>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    return 0;
   } else if constexpr (N == 256) {
-    fft_pass<256, 4, 1>(b0, b1, tw, lane); STFT_WAVE_SYNC();
-    fft_pass<256, 4, 4>(b1, b0, tw, lane); STFT_WAVE_SYNC();
-    fft_pass<256, 4, 16>(b0, b1, tw, lane); STFT_WAVE_SYNC();
-    fft_pass<256, 4, 64>(b1, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 1>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 4>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 16>(b0, b0, tw, lane); STFT_WAVE_SYNC();
+    fft_pass<256, 4, 64>(b0, b0, tw, lane); STFT_WAVE_SYNC();
     return 0;
   } else {
     static_assert(N == 1024, "n_fft 256, 512 or 1024");
@@ -97,14 +100,20 @@ __device__ __forceinline__ int fft_forward(float2* b0, float2* b1, const float2*
     return 0;
   }
 }
+// In-kernel noise, counter layout (Philox4x32-10 block = four normals): block ((fid * 8 + jp) * 64 + lane) = re / im of bins f0 = lane + 128 jp and
+// f0 + 64 of frame fid, for the bins below n_fft / 2; the LAST bin (n_fft / 2, present when n_bins_out = n_fft / 2 + 1) of both frames of a pair
+// takes block ((fid0 * 8 + 7) * 64) = (re, im) of frame fid0, (re, im) of frame fid0 + 1.  A wave evaluates that block for its next 64 pairs
+// in one call (lane k = the pair of iteration k) and hands the values out by v_readlane -- round 4: as a third pass of the bin loop the one
+// extra bin cost a whole wave-wide Philox call per frame, a third of the kernel's generator work.
 template <int NFFT, int STFT_FPB>
 __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
     const float* __restrict__ audio, int64_t audio_stride, int length, const float* __restrict__ window, int hop,
     int n_frames, int n_bins_out, int total_frames, float* __restrict__ y, float* __restrict__ x,
     const float* __restrict__ noise, float sigma, uint64_t seed, float* __restrict__ clip_absmax) {
-  __shared__ float2 buf[2][STFT_FPB][NFFT];
+  constexpr int NBUF = NFFT == 1024 ? 2 : 1;     // 512 / 256 points transform in place
+  __shared__ float2 buf[NBUF][STFT_FPB][NFFT];
   __shared__ float2 tw[NFFT];                    // exp(-2 pi i q / N) for q < N (the radix-8 / radix-4 passes index up to 7 k N / (8 P) < N)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int q = threadIdx.x; q < NFFT; q += blockDim.x) {
     float s, c;
     sincospif(-2.0f * (float)q / (float)NFFT, &s, &c);
@@ -113,7 +122,17 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
   __syncthreads();
   const int64_t plane = (int64_t)n_frames * n_bins_out;
   const int npairs = (total_frames + 1) / 2;
-  for (int pid = blockIdx.x * STFT_FPB + wv; pid < npairs; pid += gridDim.x * STFT_FPB) {
+  const int n_low = n_bins_out < NFFT / 2 ? n_bins_out : NFFT / 2;      // bins served by the paired blocks
+  const bool last_bin = n_bins_out > NFFT / 2;
+  const bool gen_last = last_bin && x != nullptr && noise == nullptr;
+  const int pid_step = gridDim.x * STFT_FPB;
+  float nyq[4] = {0.f, 0.f, 0.f, 0.f};
+  int it = 0;
+  for (int pid = blockIdx.x * STFT_FPB + wv; pid < npairs; pid += pid_step, ++it) {
+    if (gen_last && (it & 63) == 0) {
+      const int64_t pk = (int64_t)pid + (int64_t)lane * pid_step;       // the pair of iteration it + lane
+      philox_normal4(seed, ((uint64_t)(2 * pk) * 8 + 7) * 64, nyq);
+    }
     const int fid0 = 2 * pid, fid1 = fid0 + 1;
     const bool two_frames = fid1 < total_frames;
     const int b0 = fid0 / n_frames, t0 = fid0 % n_frames;
@@ -130,13 +149,14 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
       buf[0][wv][n] = make_float2(a0[j0] * wn, two_frames ? a1[j1] * wn : 0.f);
     }
     STFT_WAVE_SYNC();
-    const int cur = fft_forward<NFFT>(&buf[0][wv][0], &buf[1][wv][0], tw, lane);
+    const int cur = fft_forward<NFFT>(&buf[0][wv][0], &buf[NBUF - 1][wv][0], tw, lane);
     // ---- separate the two spectra and write them (+ the noisy copies); `fr` = 0 / 1 selects the frame of the pair
 #pragma unroll
     for (int fr = 0; fr < 2; ++fr) {
       if (fr == 1 && !two_frames) break;
       const int fid = fr ? fid1 : fid0, b = fr ? b1 : b0, t = fr ? t1 : t0;
-      float* yre = y + ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out;
+      const int64_t row = ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out;
+      float* yre = y + row;
       float* yim = yre + plane;
       float amax = 0.f;
       auto bin = [&](int f) __attribute__((always_inline)) {
@@ -144,16 +164,16 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
         return fr == 0 ? make_float2(0.5f * (z.x + zn.x), 0.5f * (z.y - zn.y)) : make_float2(0.5f * (z.y + zn.y), -0.5f * (z.x - zn.x));
       };
       // bins in pairs (f, f + 64): one Philox block = four normals = the noise of both
-      for (int f0 = lane, jp = 0; f0 < n_bins_out; f0 += 128, ++jp) {
+      for (int f0 = lane, jp = 0; f0 < n_low; f0 += 128, ++jp) {
         const int f1 = f0 + 64;
-        const bool two = f1 < n_bins_out;
+        const bool two = f1 < n_low;
         const float2 v0 = bin(f0), v1 = two ? bin(f1) : make_float2(0.f, 0.f);
         yre[f0] = v0.x;
         yim[f0] = v0.y;
         if (two) { yre[f1] = v1.x; yim[f1] = v1.y; }
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v1.x), fabsf(v1.y))));
         if (x != nullptr) {
-          const int64_t o0 = ((int64_t)b * 2) * plane + (int64_t)t * n_bins_out + f0;
+          const int64_t o0 = row + f0;
           float g[4];
           if (noise != nullptr) {
             g[0] = noise[o0];
@@ -168,6 +188,22 @@ __global__ __launch_bounds__(64 * STFT_FPB) void stft_kernel(
           if (two) {
             x[o0 + 64] = v1.x + sigma * g[2];
             x[o0 + 64 + plane] = v1.y + sigma * g[3];
+          }
+        }
+      }
+      if (last_bin) {
+        // the values of this pair sit in lane (it & 63) of the block evaluated above
+        const float gre = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq[2 * fr]), it & 63));
+        const float gim = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq[2 * fr + 1]), it & 63));
+        if (lane == 0) {
+          const float2 v = bin(NFFT / 2);
+          const int64_t o = row + NFFT / 2;
+          yre[NFFT / 2] = v.x;
+          yim[NFFT / 2] = v.y;
+          amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+          if (x != nullptr) {
+            x[o] = v.x + sigma * (noise != nullptr ? noise[o] : gre);
+            x[o + plane] = v.y + sigma * (noise != nullptr ? noise[o + plane] : gim);
           }
         }
       }

@@ -55,6 +55,30 @@ def test_stft_device_noise_statistics():
     assert torch.equal(x3, x)                     # same seed, same draw
 
 
+def test_stft_device_noise_last_bin_and_grid_independence():
+    """The bin n_fft / 2 takes its noise from a per-PAIR Philox block that a wave evaluates for its next 64 pairs at once (stft.hip): the
+    draw must not depend on how the pairs are dealt to the waves (a 256-clip launch walks two pairs per wave, an 8-clip launch one), the
+    last bin must be N(0, sigma^2) like the others, and no two frames may share its values."""
+    import maavss_amd
+    from oracle import stft_ref_cpu as sref
+    hop, length, t_a = maavss_amd.calc_hop_size(16, 8, 30, 16000)
+    audio = sref.synthetic_audio(264, length, 7).cuda()
+    for fft_len in (512, 256, 1024):
+        st = maavss_amd.STFT(fft_len, hop, noise_std=0.1, device="cuda")
+        x_big, y_big = st(audio, seed=5)
+        x_small, y_small = st(audio[:8].contiguous(), seed=5)
+        assert torch.equal(y_big[:8], y_small)
+        assert torch.equal(x_big[:8], x_small), fft_len
+        d = ((x_big - y_big)[..., fft_len // 2] / 0.1).double()          # [264, 2, t_a]: the last bin, re and im planes
+        assert abs(d.mean().item()) < 2e-2 and abs(d.std().item() - 1) < 2e-2, (fft_len, d.mean().item(), d.std().item())
+        assert abs((d ** 4).mean().item() - 3) < 0.15
+        flat = d.flatten()
+        assert flat.unique().numel() > 0.999 * flat.numel()               # frames do not share draws
+        # neighbouring frames (the two halves of a pair, and consecutive pairs) are uncorrelated
+        c1 = (d[:, :, 1:] * d[:, :, :-1]).mean().item()
+        assert abs(c1) < 2e-2, c1
+
+
 @pytest.mark.parametrize("fft_len,hop,frames,trim,normalized", [(512, 66, 64, False, True), (256, 66, 64, False, True),
                                                                 (512, 66, 128, True, True), (1024, 100, 40, False, False)])
 def test_istft_matches_oracle(fft_len, hop, frames, trim, normalized):
