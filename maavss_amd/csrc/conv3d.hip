@@ -104,13 +104,18 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x_);
   using E = typename M::elem;
   constexpr int ES = sizeof(E), EPC = 16 / ES;       // elements per 16-byte chunk
-  constexpr int RBH = CIN * ES, NCH = RBH / 16;       // halo: bytes / chunks per position
+  // 16-bit input with 64 channels: the halo is staged in two halves of 32 channels (K order kd, half, tap, channel): 25.6 KB by LDS-DMA
+  // like the 32-channel variants instead of 51 KB through a 100-register prefetch -- three to four workgroups per CU instead of two
+  constexpr bool HSPLIT = PRECISE != MODE_F32 && CIN == 64;      // (also for f32 input: the two input forms stay bit-identical)
+  constexpr int CH = HSPLIT ? 32 : CIN;               // channels per halo stage
+  constexpr int NH = CIN / CH;                        // halo stages per kd plane
+  constexpr int RBH = CH * ES, NCH = RBH / 16;        // halo: bytes / chunks per position
   constexpr int RBW = 64 * ES, NCW = RBW / 16;        // weight tile: bytes / chunks per row (64 k)
   constexpr int NT = COUT / 16;
-  constexpr int NCHUNK = (25 * CIN + 63) / 64;
+  constexpr int NCHUNK = (25 * CH + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  E* halo = reinterpret_cast<E*>(smem);                         // [20*20][CIN] swizzled
-  E* wl = halo + 400 * CIN;                                     // [2][COUT][64] swizzled
+  E* halo = reinterpret_cast<E*>(smem);                         // [20*20][CH] swizzled
+  E* wl = halo + 400 * CH;                                      // [2][COUT][64] swizzled
   float* red = reinterpret_cast<float*>(wl + 2 * COUT * 64);    // [4][2][COUT] stats scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   // so the 100 staging registers are free.  (Scratch build without the halo loads: igemm 4.3 -> 2.9 ms per step.)
   // The smaller C_in variants run 3 - 5 workgroups per CU and keep the plain loop (batched loads cost them occupancy).
   constexpr int VE = IN16 ? 8 : 4;                      // elements per 16-byte global vector
-  constexpr int HV = 400 * (CIN / VE), NV = (HV + 255) / 256;
-  constexpr bool PREFETCH = CIN >= 64;
+  constexpr int HV = 400 * (CH / VE), NV = (HV + 255) / 256;
+  constexpr bool PREFETCH = CIN >= 64 && !HSPLIT;
   float4 hv[PREFETCH ? NV : 1];                         // IN16: the same 16 bytes hold 8 operand elements
   auto fetch = [&](int kd) __attribute__((always_inline)) {
     const int64_t plane = (int64_t)(bt + kd - 1) * H * W * CIN;
@@ -172,18 +177,18 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   };
   const int kd_lo = t == 0 ? 1 : 0, kd_hi = t == T - 1 ? 1 : 2;   // frames t + kd - 1 inside the clip (block-uniform)
   if constexpr (PREFETCH) fetch(kd_lo);
-  for (int kd = kd_lo; kd <= kd_hi; ++kd) {
+  for (int kd = kd_lo; kd <= kd_hi; ++kd)
+  for (int hh = 0; hh < NH; ++hh) {
     __syncthreads();
-    // ---- stage the 20x20xCIN halo of frame t + kd - 1 (zero-filled outside the image)
+    // ---- stage the 20x20xCH halo of frame t + kd - 1 (zero-filled outside the image)
     if constexpr (PREFETCH) {
       stash();
     } else if constexpr (IN16) {
       // LDS-DMA: 16 B per lane straight into the halo image.  The DMA writes lane-linearly (slot i = position i / NCH, physical
       // chunk i % NCH), so the swizzle is applied on the SOURCE side (XOR: its own inverse).  Positions outside the image read
-      // the zero padding at the end of weight row 0 (k >= 25 C_in; 96 / 64 bytes for C_in = 16 / 32) -- no predication, the
+      // the zero padding at the end of weight row 0 (k >= 25 C_in: maavss_conv3d_kp leaves at least 64 bytes) -- no predication, the
       // wave stays whole, the destination base stays lane 0's.
-      static_assert(CIN == 16 || CIN == 32, "the zero source relies on the padded tail of the weight rows");
-      const unsigned short* xp = x16 + (int64_t)(bt + kd - 1) * H * W * CIN;
+      const unsigned short* xp = x16 + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
       const unsigned short* zeros = reinterpret_cast<const unsigned short*>(wt) + 25 * CIN;
       for (int i0 = 0; i0 < HV; i0 += 256) {
         const int i = i0 + tid;
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
         }
       }
     } else {
-      const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN;
+      const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
       for (int i = tid; i < HV; i += 256) {
-        const int pos = i / (CIN / 4), c4 = (i % (CIN / 4)) * 4;
+        const int pos = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
         const int r = pos / 20, c = pos % 20;
         const int iy = y0 + r - pad, ix = x0 + c - pad;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -209,12 +214,17 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
         d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
       }
     }
-    // ---- weight chunk 0 of this kd
+    // ---- weight chunks of this (kd, half).  Source of the 16-byte piece c of row n of chunk q: k = 64 q + 8 c, or with the halo in
+    // halves k = (2 q + c / 4) * 64 + 32 half + 8 (c % 4) -- two taps x 32 channels; the phantom tap 25 of the last chunk is the zero tail
     const E* wk = wt + (int64_t)kd * COUT * KP;
+    auto wsrc = [&](int i, int q) __attribute__((always_inline)) {
+      const int n = i / NCW, c = i % NCW;
+      if constexpr (HSPLIT) return wk + (int64_t)n * KP + (2 * q + c / 4) * 64 + hh * 32 + (c % 4) * EPC;
+      else return wk + (int64_t)n * KP + q * 64 + c * EPC;
+    };
     for (int i = tid; i < COUT * NCW; i += 256) {
       const int n = i / NCW, c = i % NCW;
-      *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) =
-          *reinterpret_cast<const uint4*>(wk + (int64_t)n * KP + c * EPC);
+      *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) = *reinterpret_cast<const uint4*>(wsrc(i, 0));
     }
     if constexpr (IN16 && !PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo DMA has landed
     __syncthreads();
@@ -231,15 +241,15 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
         for (int v = 0; v < WV; ++v) {
           int i = v * 256 + tid;
           i = i < COUT * NCW ? i : 0;
-          wreg[v] = *reinterpret_cast<const uint4*>(wk + (int64_t)(i / NCW) * KP + chn * 64 + (i % NCW) * EPC);
+          wreg[v] = *reinterpret_cast<const uint4*>(wsrc(i, chn));
         }
       }
       const E* wb = wl + (ch & 1) * COUT * 64;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kk = ch * 64 + s * 32 + 8 * g;
-        int tap = kk / CIN;
-        const int ci = kk % CIN;
+        int tap = kk / CH;
+        const int ci = kk % CH;
         tap = tap > 24 ? 24 : tap;  // padded tail: weights are zero there
         const int kh = tap / 5, kw = tap % 5;
         typename M::frag fa[4], fb[NT];
@@ -329,7 +339,7 @@ template <int PRECISE, int CIN, int COUT, bool IN16 = false>
 static int launch_igemm(const void* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
                         int Wo, int pad, int KP, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
-  const size_t smem = (400 * CIN + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
+  const size_t smem = (400 * (PRECISE != MODE_F32 && CIN == 64 ? 32 : CIN) + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
   auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT, IN16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
@@ -337,7 +347,9 @@ static int launch_igemm(const void* x, const void* wt, float* y, float* stats, i
   return 0;
 }
 
-extern "C" int maavss_conv3d_kp(int c_in) { return ((25 * c_in + 63) / 64) * 64; }
+// padded K of a weight row: a multiple of 64 that leaves at least 32 zero elements (64 bytes) behind the 25 C_in real ones -- the zero source of
+// the halo LDS-DMA and the phantom tap of the split-halo variants
+extern "C" int maavss_conv3d_kp(int c_in) { return ((25 * c_in + 32 + 63) / 64) * 64; }
 
 extern "C" int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, int c_in, int mode, int precise, void* stream) {
   MAAVSS_CHECK_ARG(w && wt, "conv3d_prep_weights: null pointer");
