@@ -15,6 +15,8 @@
 //                    owns one (kd,kh) and the 5 kw taps, walks a chunk of position tiles and writes a
 //                    partial; a second kernel sums the chunks (deterministic, no atomics).
 #include <type_traits>
+#include <utility>
+#include <cstdlib>
 #include "mma.h"
 
 // --------------------------------------------------------------------------------------------
@@ -347,6 +349,253 @@ static int launch_igemm(const void* x, const void* wt, float* y, float* stats, i
   return 0;
 }
 
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant in the body
+template <class F, int... S>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// --------------------------------------------------------------------------------------------
+// The 16-bit modes of the implicit GEMM (round 4): the tile, the K order (kd, 32-channel half of a 64-channel input, tap, channel), the halo
+// image and the epilogue of conv3d_igemm_kernel, with the inner loop rebuilt around what its counters showed (35-45 % matrix-pipe busy, 3-4.5
+// vector instructions per MFMA, waves waiting 45-64 % of their cycles; profiles/r3_e_kernel_pmc.json):
+//   * the 13 / 25 K steps of a halo stage are unrolled with the tap as a compile-time constant: a lane keeps one swizzled byte offset per
+//     kw (32-channel stages) or one offset + a per-step select (16-channel stages: a 32-deep step spans two taps), the row / tap part is the
+//     ds_read's immediate -- no address arithmetic in the loop;
+//   * the fragments of step t + 1 are read before the MFMAs of step t (two register sets);
+//   * the weight chunks (64 k) go through a ring of three LDS tiles: chunk c + 2 is written while chunk c computes, so the fragments of the
+//     next chunk can be read before the barrier that ends this one; the barrier waits for LDS only (the global loads of chunk c + 3 are
+//     issued behind it and stay in flight for a whole chunk).
+template <int PRECISE, int CIN, int COUT, bool IN16>
+__global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restrict__ x_, const typename Mma<PRECISE>::elem* __restrict__ wt,
+                                                             float* __restrict__ y, float* __restrict__ stat_partials, int n_bt, int T, int H,
+                                                             int W, int Ho, int Wo, int pad, int KP) {
+  using M = Mma<PRECISE>;
+  using E = typename M::elem;
+  static_assert(PRECISE != MODE_F32 && sizeof(E) == 2, "16-bit MFMA modes only");
+  constexpr int CH = CIN == 64 ? 32 : CIN;            // channels per halo stage
+  constexpr int NH = CIN / CH;                        // halo stages per kd plane
+  constexpr int PB = CH * 2;                          // bytes per halo position
+  constexpr int NCH = PB / 16;                        // 16-byte chunks per halo position
+  constexpr int NT = COUT / 16;
+  constexpr int STEPS = (25 * CH + 31) / 32;          // 32-deep K steps per stage: 13 (two taps each, the last half phantom) or 25 (one tap each)
+  constexpr int NCHUNK = (STEPS + 1) / 2;             // 64-k weight chunks per stage
+  constexpr int WB = COUT * 128;                      // bytes of one weight tile [COUT][64]
+  constexpr int WV = (COUT * 8 + 255) / 256;          // 16-byte pieces of a weight tile per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;                                  // [400][PB], chunk-swizzled (swz_halo)
+  char* ring = smem + 400 * PB;                       // [3][COUT][128 B], chunk ^= (n >> 1) & 7
+  float* red = reinterpret_cast<float*>(ring + 3 * WB);
+  const float* x = reinterpret_cast<const float*>(x_);
+  const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x_);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const TileId tile = xcd_tile((Wo + 15) / 16, (Ho + 15) / 16, (int64_t)((Wo + 15) / 16) * ((Ho + 15) / 16) * n_bt);
+  if (!tile.valid) return;
+  const int x0 = tile.tx * 16, y0 = tile.ty * 16;
+  const int bt = tile.bt, t = bt % T;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-lane LDS byte offsets.  A (halo): position (row 4 wv + i + kh, column l16 + kw), chunk = the lane's 8 channels
+  unsigned a_off[CH == 32 ? 5 : 1];
+  if constexpr (CH == 32) {
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const int c = l16 + kw;
+      a_off[kw] = (unsigned)(((4 * wv * 20 + c) * NCH + swz_halo<PB, 2>(c, g)) * 16);
+    }
+  } else {
+    a_off[0] = (unsigned)(((4 * wv * 20 + l16) * NCH + (g & 1)) * 16);      // + tap offset of the lane's half of the step
+  }
+  // B (weight tile): row n = 16 j + l16, chunk 4 s + g of the row, swizzled with (n >> 1) & 7 = (l16 >> 1) & 7
+  unsigned b_off[2];
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) b_off[sp] = (unsigned)((l16 * 8 + ((sp * 4 + g) ^ ((l16 >> 1) & 7))) * 16);
+
+  typename M::frag fa[2][4], fb[2][NT];
+  // fragments of step `st` (compile-time) of the current stage into register set `set`; `slot_b` = byte offset of the ring tile of its chunk
+  auto load_frags = [&](auto st_c, int set, unsigned slot_b) __attribute__((always_inline)) {
+    constexpr int st = decltype(st_c)::value;
+    unsigned ab;
+    int imm;                                           // compile-time part of the A address (rows / taps)
+    if constexpr (CH == 32) {
+      constexpr int kh = st / 5, kw = st % 5;
+      ab = a_off[kw];
+      imm = kh * 20 * PB;
+    } else {
+      constexpr int t0 = 2 * st, t1 = 2 * st + 1 > 24 ? 24 : 2 * st + 1;       // tap 25 is the zero tail of the weight rows
+      constexpr int o0 = ((t0 / 5) * 20 + t0 % 5) * PB, o1 = ((t1 / 5) * 20 + t1 % 5) * PB;
+      ab = a_off[0] + (g >= 2 ? (unsigned)o1 : (unsigned)o0);
+      imm = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const typename M::frag*>(halo + ab + imm + i * 20 * PB);
+    const unsigned bb = slot_b + b_off[st & 1];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[set][j] = *reinterpret_cast<const typename M::frag*>(ring + bb + j * 16 * 128);
+  };
+  auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[set][i], fb[set][j]);
+  };
+
+  // ---- weight tiles: piece i of a tile = 16 bytes (row n = i / 8, chunk c = i % 8)
+  const int kd_lo = t == 0 ? 1 : 0, kd_hi = t == T - 1 ? 1 : 2;   // frames t + kd - 1 inside the clip (block-uniform)
+  uint4 wreg[WV];
+  auto w_load = [&](const E* wk, int hh, int q, uint4 (&dst)[WV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+      int i = v * 256 + tid;
+      i = i < COUT * 8 ? i : 0;                        // unconditional (clamped) loads keep the array in registers
+      const int n = i >> 3, c = i & 7;
+      const E* src = CIN == 64 ? wk + (int64_t)n * KP + (2 * q + (c >> 2)) * 64 + hh * 32 + (c & 3) * 8 : wk + (int64_t)n * KP + q * 64 + c * 8;
+      dst[v] = *reinterpret_cast<const uint4*>(src);
+    }
+  };
+  auto w_store = [&](int slot, const uint4 (&src)[WV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+      const int i = v * 256 + tid;
+      if (i < COUT * 8) {
+        const int n = i >> 3, c = i & 7;
+        *reinterpret_cast<uint4*>(ring + slot * WB + (n * 8 + (c ^ ((n >> 1) & 7))) * 16) = src[v];
+      }
+    }
+  };
+
+  for (int kd = kd_lo; kd <= kd_hi; ++kd)
+  for (int hh = 0; hh < NH; ++hh) {
+    // (every wave is past its last read of the previous stage's halo and ring: the barrier that ended its last chunk)
+    // ---- halo of frame t + kd - 1, channels [hh CH, hh CH + CH), zero outside the image
+    if constexpr (IN16) {
+      // LDS-DMA, 16 B per lane, lane-linear destination: the swizzle is applied on the SOURCE side (XOR: its own inverse); positions outside
+      // the image read the zero tail of weight row 0 (k >= 25 C_in: maavss_conv3d_kp leaves at least 64 bytes)
+      const unsigned short* xp = x16 + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
+      const unsigned short* zeros = reinterpret_cast<const unsigned short*>(wt) + 25 * CIN;
+      int tv = tid;
+      asm volatile("" : "+v"(tv));   // the index arithmetic is redone per stage: hoisted out of the stage loop it costs 60 registers
+      for (int i0 = 0; i0 < 400 * NCH; i0 += 256) {
+        const int i = i0 + tv;
+        if (i < 400 * NCH) {
+          const int pos = i / NCH, pc = i % NCH;
+          const int r = pos / 20, c = pos % 20;
+          const int iy = y0 + r - pad, ix = x0 + c - pad;
+          const unsigned short* src = zeros;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) src = xp + ((int64_t)iy * W + ix) * CIN + swz_halo<PB, 2>(c, pc) * 8;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(halo + (int64_t)i * 16), 16, 0, 0);
+        }
+      }
+    } else {
+      const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      for (int i = tv; i < 400 * (CH / 4); i += 256) {
+        const int pos = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
+        const int r = pos / 20, c = pos % 20;
+        const int iy = y0 + r - pad, ix = x0 + c - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xp + ((int64_t)iy * W + ix) * CIN + c4);
+        E* d = reinterpret_cast<E*>(halo + (pos * NCH + swz_halo<PB, 2>(c, c4 / 8)) * 16) + (c4 % 8);
+        d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
+      }
+    }
+    // ---- weight chunks 0 and 1 of the stage into ring tiles 0 and 1, chunk 2 on its way
+    const E* wk = wt + (int64_t)kd * COUT * KP;
+    {
+      uint4 w0[WV];
+      w_load(wk, hh, 0, w0);
+      w_load(wk, hh, 1, wreg);
+      w_store(0, w0);
+      w_store(1, wreg);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // halo (DMA or stores) and the two tiles have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (NCHUNK > 2) w_load(wk, hh, 2, wreg);
+    load_frags(std::integral_constant<int, 0>{}, 0, 0u);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the K steps of the stage
+    auto step = [&](auto st_c) __attribute__((always_inline)) {
+      constexpr int st = decltype(st_c)::value;
+      constexpr int c = st / 2;                        // chunk of this step
+      if constexpr (st + 1 < STEPS) load_frags(std::integral_constant<int, st + 1>{}, (st + 1) & 1, (unsigned)((((st + 1) / 2) % 3) * WB));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(st & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((st & 1) || st + 1 == STEPS) {     // the chunk ends
+        if constexpr (c + 2 < NCHUNK) w_store((c + 2) % 3, wreg);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (c + 3 < NCHUNK) w_load(wk, hh, c + 3, wreg);
+      }
+    };
+    static_for<STEPS>(step);
+  }
+  // ---- epilogue: store + optional per-block BatchNorm partial sums (sum, sum of squares per channel)
+  float* yp = y + (int64_t)bt * Ho * Wo * COUT;
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oy = y0 + wv * 4 + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ox = x0 + g * 4 + r;
+      if (oy < Ho && ox < Wo) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float v = acc[i][j][r];
+          yp[((int64_t)oy * Wo + ox) * COUT + j * 16 + l16] = v;
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      }
+    }
+  }
+  if (stat_partials != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s1[j] = rows4_sum(s1[j]);
+      s2[j] = rows4_sum(s2[j]);
+      if (g == 0) {
+        red[(wv * 2 + 0) * COUT + j * 16 + l16] = s1[j];
+        red[(wv * 2 + 1) * COUT + j * 16 + l16] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const float v = red[tid] + red[2 * COUT + tid] + red[4 * COUT + tid] + red[6 * COUT + tid];
+      stat_partials[tile.lin * 2 * COUT + tid] = v;
+    }
+  }
+}
+
+template <int PRECISE, int CIN, int COUT, bool IN16>
+static int launch_igemm16(const void* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho, int Wo, int pad, int KP,
+                          hipStream_t st) {
+  if constexpr (COUT > 32) {            // not instantiated: see maavss_conv3d_igemm
+    return launch_igemm<PRECISE, CIN, COUT, IN16>(x, wt, y, stats, B, T, H, W, Ho, Wo, pad, KP, st);
+  } else {
+    using E = typename Mma<PRECISE>::elem;
+    const size_t smem = 400 * (CIN == 64 ? 32 : CIN) * 2 + 3 * COUT * 128 + 8 * COUT * sizeof(float);
+    auto kern = conv3d_igemm16_kernel<PRECISE, CIN, COUT, IN16>;
+    if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP);
+    return 0;
+  }
+}
+
 // padded K of a weight row: a multiple of 64 that leaves at least 32 zero elements (64 bytes) behind the 25 C_in real ones -- the zero source of
 // the halo LDS-DMA and the phantom tap of the split-halo variants
 extern "C" int maavss_conv3d_kp(int c_in) { return ((25 * c_in + 32 + 63) / 64) * 64; }
@@ -376,13 +625,22 @@ extern "C" int maavss_conv3d_igemm(const void* x, const void* wt, float* y, floa
   MAAVSS_CHECK_ARG((int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T < (1LL << 31) - 8, "conv3d_igemm: too many output tiles");
   const int KP = maavss_conv3d_kp(c_in);
   hipStream_t st = (hipStream_t)stream;
+  // 16-bit modes: the pipelined kernel for C_out <= 32 (fwd 16->32 657 -> 585 us, dgrad 64->32 553 -> 520, dgrad 32->16 646 -> 565 at the benched
+  // shape, scripts/igemm_bench.py); with 64 output channels its two fragment sets + 64 accumulators do not fit three waves per SIMD (176-188
+  // registers, or spills) and the older loop -- 16 MFMAs per fragment set, three workgroups per CU -- stays 30 % faster.  MAAVSS_IGEMM_OLD=1: A/B switch.
+  static const bool env_old16 = getenv("MAAVSS_IGEMM_OLD") != nullptr;
+  const bool old16 = env_old16 || c_out > 32;
 #define CASE(CI, CO)                                                                                          \
   if (c_in == CI && c_out == CO) {                                                                            \
     if (precise == MODE_F32) launch_igemm<MODE_F32, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);      \
-    else if (precise == MODE_F16 && x16) launch_igemm<MODE_F16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
-    else if (precise == MODE_F16) launch_igemm<MODE_F16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
-    else if (x16) launch_igemm<MODE_BF16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
-    else launch_igemm<MODE_BF16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                        \
+    else if (old16 && precise == MODE_F16 && x16) launch_igemm<MODE_F16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else if (old16 && precise == MODE_F16) launch_igemm<MODE_F16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else if (old16 && x16) launch_igemm<MODE_BF16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
+    else if (old16) launch_igemm<MODE_BF16, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                        \
+    else if (precise == MODE_F16 && x16) launch_igemm16<MODE_F16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else if (precise == MODE_F16) launch_igemm16<MODE_F16, CI, CO, false>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st); \
+    else if (x16) launch_igemm16<MODE_BF16, CI, CO, true>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);         \
+    else launch_igemm16<MODE_BF16, CI, CO, false>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);                        \
     MAAVSS_LAUNCH_CHECK("conv3d_igemm_kernel");                                                               \
     return MAAVSS_OK;                                                                                         \
   }
