@@ -33,7 +33,8 @@ extern "C" {
  *        maavss_stft_fwd's in-kernel noise changed (same seed, different noise)
  *   400  round 4: maavss_set_deterministic_workspace takes the stream the scratch is bound to; NULL ln_gamma / ln_beta = LayerNorm without
  *        the affine part; epilogue 4 of maavss_vit_ws_gemm (GELU in packed half); the in-kernel noise of maavss_stft_fwd draws the bin n_fft / 2
- *        from its own per-frame-pair Philox block (same seed, different noise in that bin); see INTEGRATION.md */
+ *        from its own per-frame-pair Philox block (same seed, different noise in that bin); maavss_bn_pool_act_fwd and
+ *        maavss_conv3d_c1_bn_pool_act take an out_bf16 pointer behind out16, maavss_conv3d_wgrad's dy16 became the mask in16; see INTEGRATION.md */
 #define MAAVSS_ABI_VERSION 400
 const char* maavss_last_error(void);
 int maavss_version(void);
@@ -98,8 +99,10 @@ int maavss_conv3d_prep_weights(const float* w, void* wt, int c_out, int c_in, in
 int maavss_conv3d_igemm(const void* x, const void* wt, float* y, float* stat_partials, int B, int T, int H, int W,
                         int c_in, int c_out, int pad, int precise, int x16, void* stream);
 int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk);
-int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
-                        int c_in, int c_out, int pad, int beta, int precise, int dy16, void* stream);
+/* in16: bit 0 = dy is bf16 (precise = 0), bit 1 = x is bf16 as well (needs bit 0 and one of the shapes 16->32, 32->64, 64->64: both operand
+ * images then go global -> LDS by DMA, no conversion); any combination gives the same dw bit for bit. */
+int maavss_conv3d_wgrad(const void* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H, int W,
+                        int c_in, int c_out, int pad, int beta, int precise, int in16, void* stream);
 /* first layer (C_in = 1, pad 2): x [B][T][H][W], w [16][1][3][5][5], w16_ws 1200 floats scratch,
  * y [B][T][H][W][16]; stat_partials [maavss_conv3d_c1_fwd_nparts(...)][2][16] (one row per workgroup: the MFMA form walks
  * 8 tiles per workgroup); wgrad ws = nchunk*1200 floats. */
@@ -131,7 +134,8 @@ int maavss_conv3d_c1_wgrad_bn(const float* x, const float* y, const float* dout,
 int maavss_conv3d_c1_stats(const float* x, const float* w, const float* gamma, float* y, float* stat_partials, int B, int T, int H,
                            int W, void* stream);
 int maavss_conv3d_c1_bn_pool_act(const float* x, const float* w, const float* mean, const float* invstd, const float* gamma,
-                                 const float* beta, float* out, void* out16, void* argmax, int B, int T, int H, int W, void* stream);
+                                 const float* beta, float* out, void* out16, void* out_bf16 /* nullable, as maavss_bn_pool_act_fwd's */,
+                                 void* argmax, int B, int T, int H, int W, void* stream);
 int maavss_conv3d_c1_wgrad_bn_recompute(const float* x, const float* w, const float* dout, const void* argmax, const float* mean,
                                         const float* invstd, const float* bn_beta, const float* coef, int pool, float* dw, float* ws,
                                         int nchunk, int B, int T, int H, int W, int beta, void* stream);
@@ -157,6 +161,8 @@ int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invst
                            int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
                            void* out16 /* nullable: IEEE-half copy of the pooled activation, contiguous channels-last
                                           [B][T][Hp][Wp][C] -- the operand format of the next Conv3d's forward MFMA */,
+                           void* out_bf16 /* nullable: the same as bf16 -- the x operand of the next Conv3d's weight gradient
+                                             (maavss_conv3d_wgrad, in16 bit 1) */,
                            void* stream);
 /* beta (nullable): with it, LeakyReLU layers recover the normalised input at the pooled maximum from `out` instead of
  * gathering it from y (xhat = (leaky^-1(out) - beta) / gamma; channels with |gamma| < 1e-2 still gather).  dy NULL: only

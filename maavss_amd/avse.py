@@ -491,7 +491,12 @@ class AV_Fusion_Model_Frames(nn.Module):
         # (the rounding the next conv's MFMA staging would apply, done once), so that conv reads half the bytes and copies;
         # the f32 tensor stays for the backward pass (weight gradient operand, BatchNorm / LeakyReLU backward).
         act_in = x_v.view(b, t, w, w)
-        act_in16 = None
+        act_in16 = act_inb = None
+        # training, 16-bit backward: the producers also write a bf16 copy of every activation whose consumer's weight gradient takes one
+        # (ops.WGRAD_X16_SHAPES: that kernel then stages both operands by LDS-DMA; the rounding is the one its staging would apply)
+        # MEASURED (profiles/r4_wgrad_x16.txt): the weight-gradient launches take 5-12 % less with a bf16 x, the step does not move (829-831 without,
+        # 828-829 clips/s with, same box: the copies cost the producers what the consumers gain) -- off unless MAAVSS_WGRAD_X16=1
+        want_b = train and not self.precise_bwd and os.environ.get("MAAVSS_WGRAD_X16", "0") == "1"
         for i in range(5):
             conv, bn = self._vis(i)
             co, pad, pool = conv.out_channels, _VIS_PAD[i], _VIS_POOL[i]
@@ -510,22 +515,28 @@ class AV_Fusion_Model_Frames(nn.Module):
                 mean, invstd = self._bn_train_stats(part, b * t * hh * ww, bn)
             else:
                 mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
-            act_in16 = None
+            x_b = act_inb
+            act_in16 = act_inb = None
+            nxt = (co, self._vis(i + 1)[0].out_channels) if i < 4 else None
+            wb = want_b and nxt in ops.WGRAD_X16_SHAPES
             if recompute:
-                out, arg, act_in16 = ops.conv3d_c1_bn_pool_act(act_in, conv.weight.detach(), mean, invstd, bn.weight.detach(), bn.bias.detach())
+                res = ops.conv3d_c1_bn_pool_act(act_in, conv.weight.detach(), mean, invstd, bn.weight.detach(), bn.bias.detach(), want_bf16=wb)
+                out, arg, act_in16 = res[:3]
+                act_inb = res[3] if wb else None
                 strides = None
             elif i < 4:
                 if self.precise_fwd:
                     out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY)
                 else:
-                    out, arg, act_in16 = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
-                                                             ops.BN_LEAKY, want16=True)
+                    res = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY, want16=True, want_bf16=wb)
+                    out, arg, act_in16 = res[:3]
+                    act_inb = res[3] if wb else None
                 strides = None
             else:   # write the [B,16,T,S] block of the LSTM sequence directly (avse_model_final.py:58,239-240)
                 strides = (self.latent_channels * 2 * ts, self.s_v, 1, 2 * ts)
                 out, arg = ops.bn_pool_act_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, ops.BN_LEAKY,
                                                out=seq, strides=strides)
-            sv["vis"].append(dict(x=act_in, y=y, mean=mean, invstd=invstd, out=out, arg=arg, strides=strides, recompute=recompute))
+            sv["vis"].append(dict(x=act_in, x_bf16=x_b, y=y, mean=mean, invstd=invstd, out=out, arg=arg, strides=strides, recompute=recompute))
             act_in = out
         # --- STFT encoder (K10)
         cur, nchw = x_a, True
@@ -700,7 +711,8 @@ class AV_Fusion_Model_Frames(nn.Module):
                 if i == 0:
                     ops.conv3d_c1_wgrad(s["x"], dy, dw=buf, beta=beta)
                 else:
-                    ops.conv3d_wgrad(s["x"], dy, pad, pr_conv, dw=buf, beta=beta)
+                    xw = s["x_bf16"] if s.get("x_bf16") is not None and dy.dtype == torch.bfloat16 else s["x"]
+                    ops.conv3d_wgrad(xw, dy, pad, pr_conv, dw=buf, beta=beta)
                 out_grads[wname] = buf
             if i > 0:
                 wtd = ops.conv3d_prep(conv.weight.detach(), 1, pr_conv)

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __res
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, unsigned char* __restrict__ argmax,
-                                                              unsigned short* __restrict__ out16, PoolGeom g, int act) {
+                                                              unsigned short* __restrict__ out16, unsigned short* __restrict__ out_bf16,
+                                                              PoolGeom g, int act) {
   const int C4 = g.C >> 2;
   const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __res
     // the next Conv3d's forward MFMA rounds this activation to IEEE half when it stages it: done here once instead
     // (same rounding, same value), so that its halo becomes a plain copy of half the bytes
     if (out16 != nullptr) *reinterpret_cast<uint2*>(out16 + pos * g.C + c) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
+    if (out_bf16 != nullptr) *reinterpret_cast<uint2*>(out_bf16 + pos * g.C + c) = make_uint2(pack2<0>(a4[0], a4[1]), pack2<0>(a4[2], a4[3]));
     if (argmax != nullptr) *reinterpret_cast<uchar4*>(argmax + pos * g.C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
   }
 }
@@ -375,14 +377,14 @@ extern "C" int maavss_bn_eval_stats(const float* running_mean, const float* runn
 extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
                                       const float* beta, float* out, void* argmax, int B, int T, int H, int W, int C,
                                       int pool, int act, int64_t os_b, int64_t os_t, int64_t os_p, int64_t os_c,
-                                      void* out16, void* stream) {
+                                      void* out16, void* out_bf16, void* stream) {
   MAAVSS_CHECK_ARG(y && mean && invstd && gamma && beta && out, "bn_pool_act_fwd: null pointer");
   if (int rc = check_geom("bn_pool_act_fwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_fwd: argmax buffer required when pool > 1");
   PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
   const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * (C / 4);
   hipLaunchKernelGGL(bn_pool_act_fwd_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, (unsigned short*)out16, g, act);
+                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, (unsigned short*)out16, (unsigned short*)out_bf16, g, act);
   MAAVSS_LAUNCH_CHECK("bn_pool_act_fwd_kernel");
   return MAAVSS_OK;
 }

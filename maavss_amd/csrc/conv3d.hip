@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* _
 }
 
 int maavss_conv3d_wgrad_wide_try(const float* x, const void* dy, float* ws, int nchunk, int B, int T, int H, int W, int Ho,
-                                 int Wo, int c_in, int c_out, int pad, int mode, int dy16, hipStream_t st);  // conv3d_wgrad_wide.hip
+                                 int Wo, int c_in, int c_out, int pad, int mode, int dy16, int x16, hipStream_t st);  // conv3d_wgrad_wide.hip
 
 extern "C" int64_t maavss_conv3d_wgrad_ws_bytes(int c_in, int c_out, int nchunk) {
   return (int64_t)nchunk * 75 * c_in * c_out * 4;
@@ -842,17 +842,22 @@ static void launch_wgrad(const float* x, const void* dy, float* ws, int BT, int 
                      tiles_y, tpc, nchunk);
 }
 
-extern "C" int maavss_conv3d_wgrad(const float* x, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
-                                   int W, int c_in, int c_out, int pad, int beta, int precise, int dy16, void* stream) {
+extern "C" int maavss_conv3d_wgrad(const void* x_, const void* dy, float* dw, float* ws, int nchunk, int B, int T, int H,
+                                   int W, int c_in, int c_out, int pad, int beta, int precise, int in16, void* stream) {
+  const float* x = reinterpret_cast<const float*>(x_);
+  const int dy16 = in16 & 1, x16 = (in16 >> 1) & 1;      // bit 0: dy is bf16, bit 1: x is bf16 too
   MAAVSS_CHECK_ARG(x && dy && dw && ws, "conv3d_wgrad: null pointer");
+  MAAVSS_CHECK_ARG(in16 >= 0 && in16 <= 3, "conv3d_wgrad: in16 is a 2-bit mask (1: dy bf16, 2: x bf16)");
   MAAVSS_CHECK_ARG(!dy16 || precise == MODE_BF16, "conv3d_wgrad: a 16-bit dy is bf16 and needs precise = 0");
+  MAAVSS_CHECK_ARG(!x16 || (dy16 && ((c_in == 16 && c_out == 32) || (c_in == 32 && c_out == 64) || (c_in == 64 && c_out == 64))),
+                   "conv3d_wgrad: a bf16 x needs a bf16 dy and one of the shapes 16->32, 32->64, 64->64 (got %d->%d)", c_in, c_out);
   MAAVSS_CHECK_ARG(nchunk >= 1, "conv3d_wgrad: nchunk must be >= 1");
   MAAVSS_CHECK_ARG(precise >= 0 && precise <= 2, "conv3d_wgrad: mode must be 0 (bf16), 1 (f32) or 2 (f16)");
   const int Ho = H + 2 * pad - 4, Wo = W + 2 * pad - 4;
   MAAVSS_CHECK_ARG(Ho > 0 && Wo > 0 && B > 0 && T > 0, "conv3d_wgrad: empty output");
   hipStream_t st = (hipStream_t)stream;
   // the two large-M layers use the wide kernel (conv3d_wgrad_wide.hip): every tile staged once / three times
-  if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, dy16, st)) {
+  if (maavss_conv3d_wgrad_wide_try(x, dy, ws, nchunk, B, T, H, W, Ho, Wo, c_in, c_out, pad, precise, dy16, x16, st)) {
     MAAVSS_LAUNCH_CHECK("conv3d_wgrad_wide_kernel");
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(cdiv(75 * c_in * c_out, 16)), dim3(256), 0, st, ws, dw, nchunk, c_in,
                        c_out, beta);
@@ -1046,6 +1051,7 @@ struct C1EpiArgs {
   const float* beta;
   float* out;                     // [BT][Hp][Wp][16] pooled activation
   unsigned short* out16;          // the same as IEEE half (next conv's operand), may be null
+  unsigned short* out_bf16;       // the same as bf16 (the next conv's weight-gradient operand), may be null
   unsigned char* argmax;          // [BT][Hp][Wp][16] window position dy * 2 + dx of the maximum
   int Hp, Wp;
 };
@@ -1154,6 +1160,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_mfma_kernel(const float* __
         const int64_t pp = (((int64_t)bt * ep.Hp + py) * ep.Wp + px) * 16 + 4 * g;
         *reinterpret_cast<float4*>(ep.out + pp) = make_float4(a4[0], a4[1], a4[2], a4[3]);
         if (ep.out16 != nullptr) *reinterpret_cast<uint2*>(ep.out16 + pp) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
+        if (ep.out_bf16 != nullptr) *reinterpret_cast<uint2*>(ep.out_bf16 + pp) = make_uint2(pack2<0>(a4[0], a4[1]), pack2<0>(a4[2], a4[3]));
         *reinterpret_cast<uchar4*>(ep.argmax + pp) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
       }
     }
@@ -1608,15 +1615,16 @@ extern "C" int maavss_conv3d_c1_stats(const float* x, const float* w, const floa
 }
 
 // pass 2: conv again -> BatchNorm -> MaxPool(1,2,2) -> LeakyReLU(0.01).  out [B*T][H/2][W/2][16] f32, out16 the same as IEEE half
-// (may be null), argmax one byte per element.
+// and out_bf16 as bf16 (both may be null), argmax one byte per element.
 extern "C" int maavss_conv3d_c1_bn_pool_act(const float* x, const float* w, const float* mean, const float* invstd, const float* gamma,
-                                            const float* beta, float* out, void* out16, void* argmax, int B, int T, int H, int W,
-                                            void* stream) {
+                                            const float* beta, float* out, void* out16, void* out_bf16, void* argmax, int B, int T, int H,
+                                            int W, void* stream) {
   MAAVSS_CHECK_ARG(x && w && mean && invstd && gamma && beta && out && argmax, "conv3d_c1_bn_pool_act: null pointer");
   MAAVSS_CHECK_ARG(B > 0 && T > 0 && H >= 2 && W >= 2, "conv3d_c1_bn_pool_act: empty problem");
   MAAVSS_CHECK_ARG((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T < (1LL << 31) && (int64_t)B * T * H * W < (1LL << 40), "conv3d_c1: too many tiles");
   C1EpiArgs ep;
   ep.mean = mean; ep.invstd = invstd; ep.gamma = gamma; ep.beta = beta; ep.out = out; ep.out16 = (unsigned short*)out16;
+  ep.out_bf16 = (unsigned short*)out_bf16;
   ep.argmax = (unsigned char*)argmax; ep.Hp = H / 2; ep.Wp = W / 2;
   hipLaunchKernelGGL(conv3d_c1_fwd_mfma_kernel<2>, dim3(xcd_grid(cdiv((int64_t)cdiv(W, 16) * cdiv(H, 16) * B * T, C1_TPW))), dim3(256), 0,
                      (hipStream_t)stream, x, w, nullptr, nullptr, B * T, T, H, W, ep);

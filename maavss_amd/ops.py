@@ -91,14 +91,23 @@ def wgrad_chunks(b, t, ho, wo, ci=64, co=64):
     return max(1, min(64, tiles // 4))
 
 
+WGRAD_X16_SHAPES = ((16, 32), (32, 64), (64, 64))      # (C_in, C_out) whose weight-gradient kernel takes a bf16 x (LDS-DMA staging)
+
+
 def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
-    """dy: f32, or bfloat16 (bn_pool_act_bwd(dy_bf16=True)) with precise = MODE_BF16"""
-    _f32(x, dw)
+    """dy: f32, or bfloat16 (bn_pool_act_bwd(dy_bf16=True)) with precise = MODE_BF16; x: f32, or -- with a bfloat16 dy and one of
+    WGRAD_X16_SHAPES -- the bfloat16 copy its producer wrote (bn_pool_act_fwd(want_bf16=True)): the same result bit for bit."""
+    _f32(dw)
     dy16 = dy.dtype == torch.bfloat16
     if dy16:
         assert int(precise) == MODE_BF16 and dy.is_contiguous() and dy.is_cuda
     else:
         _f32(dy)
+    x16 = x.dtype == torch.bfloat16
+    if x16:
+        assert dy16 and x.is_contiguous() and x.is_cuda and (x.shape[-1], dy.shape[-1]) in WGRAD_X16_SHAPES
+    else:
+        _f32(x)
     b, t, h, w, ci = x.shape
     co = dy.shape[-1]
     ho, wo = h + 2 * pad - 4, w + 2 * pad - 4
@@ -110,7 +119,7 @@ def conv3d_wgrad(x, dy, pad, precise, dw=None, beta=0, nchunk=None):
         dw = torch.empty(co, ci, 3, 5, 5, device=x.device, dtype=torch.float32)
         beta = 0
     call("maavss_conv3d_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), nchunk, b, t, h, w, ci, co, pad, int(beta),
-         int(precise), int(dy16), stream_ptr())
+         int(precise), int(dy16) | (int(x16) << 1), stream_ptr())
     return dw
 
 
@@ -167,17 +176,19 @@ def conv3d_c1_stats(x, w, gamma):
     return y, part
 
 
-def conv3d_c1_bn_pool_act(x, w, mean, invstd, gamma, beta, want16=True):
-    """pass 2: conv again -> BatchNorm -> MaxPool(1,2,2) -> LeakyReLU: (out f32, argmax u8, out16 IEEE half), [B,T,H//2,W//2,16]."""
+def conv3d_c1_bn_pool_act(x, w, mean, invstd, gamma, beta, want16=True, want_bf16=False):
+    """pass 2: conv again -> BatchNorm -> MaxPool(1,2,2) -> LeakyReLU: (out f32, argmax u8, out16 IEEE half[, the bfloat16 copy with
+    want_bf16: the next layer's weight-gradient operand]), [B,T,H//2,W//2,16]."""
     _f32(x, w, mean, invstd, gamma, beta)
     b, t, h, wd = x.shape
     hp, wp = h // 2, wd // 2
     out = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.float32)
     arg = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.uint8)
     out16 = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.float16) if want16 else None
-    call("maavss_conv3d_c1_bn_pool_act", ptr(x), ptr(w), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(out16), ptr(arg),
-         b, t, h, wd, stream_ptr())
-    return out, arg, out16
+    outb = torch.empty(b, t, hp, wp, 16, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    call("maavss_conv3d_c1_bn_pool_act", ptr(x), ptr(w), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(out16), ptr(outb),
+         ptr(arg), b, t, h, wd, stream_ptr())
+    return (out, arg, out16, outb) if want_bf16 else (out, arg, out16)
 
 
 def conv3d_c1_wgrad_bn_recompute(x, w, dout, arg, mean, invstd, bn_beta, coef, pool, dw=None, beta=0, nchunk=None):
@@ -249,9 +260,10 @@ def cl_strides(t, hp, wp, c):
     return (t * hp * wp * c, hp * wp * c, c, 1)
 
 
-def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=None, want16=False):
+def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=None, want16=False, want_bf16=False):
     """y [B,T,H,W,C] -> out (default channels-last [B,T,H//p,W//p,C]) and argmax (uint8) when pool > 1.
-    want16: also return an IEEE-half copy of the pooled activation (the next Conv3d's forward MFMA operand)."""
+    want16: also return an IEEE-half copy of the pooled activation (the next Conv3d's forward MFMA operand); want_bf16: and / or a
+    bfloat16 copy (the next Conv3d's weight-gradient operand, conv3d_wgrad) -- appended to the returned tuple in that order."""
     _f32(y, mean, invstd, gamma, beta)
     b, t, h, w, c = y.shape
     hp, wp = h // pool, w // pool
@@ -260,11 +272,10 @@ def bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, act, out=None, strides=N
         strides = cl_strides(t, hp, wp, c)
     arg = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.uint8) if pool > 1 else None
     out16 = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.float16) if want16 else None
+    outb = torch.empty(b, t, hp, wp, c, device=y.device, dtype=torch.bfloat16) if want_bf16 else None
     call("maavss_bn_pool_act_fwd", ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), ptr(arg), b, t, h,
-         w, c, pool, act, *[int(s) for s in strides], ptr(out16), stream_ptr())
-    if want16:
-        return out, arg, out16
-    return out, arg
+         w, c, pool, act, *[int(s) for s in strides], ptr(out16), ptr(outb), stream_ptr())
+    return (out, arg) + ((out16,) if want16 else ()) + ((outb,) if want_bf16 else ())
 
 
 def bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, act, strides=None, dgamma=None, dbeta=None,

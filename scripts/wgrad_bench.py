@@ -29,6 +29,13 @@ for name, ci, co, hw, pad in (("16->32 @112^2", 16, 32, 112, 2), ("32->64 @56^2"
     ref = ops.conv3d_wgrad(x, dy.float(), pad, ops.MODE_F32)
     rel = ((dw - ref).norm() / ref.norm()).item()
     fl = 2.0 * 32 * 16 * ho * ho * 75 * ci * co
-    print(f"{name:16s} {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s   vs exact-f32 kernel: {rel:.2e} relative L2", flush=True)
+    extra = ""
+    if (ci, co) in getattr(ops, "WGRAD_X16_SHAPES", ()):      # x as the bf16 copy its producer writes: LDS-DMA staging
+        xb = x.bfloat16()
+        dw16 = torch.empty_like(dw)
+        us16 = timed(lambda: ops.conv3d_wgrad(xb, dy, pad, ops.MODE_BF16, dw=dw16))
+        extra = f";  bf16 x: {us16:8.1f} us {fl / us16 / 1e6:6.0f} TFLOP/s, bit-identical: {torch.equal(dw16, dw)}"
+        tot += us16 - us
+    print(f"{name:16s} {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s   vs exact-f32 kernel: {rel:.2e} relative L2{extra}", flush=True)
     tot += us
-print(f"sum {tot:.1f} us")
+print(f"sum {tot:.1f} us (with the bf16-x launches where they exist)")

@@ -64,7 +64,7 @@ def test_round3_entry_points_validate_their_arguments_before_touching_the_device
     with pytest.raises(_lib.MaavssError, match="too many tiles"):
         _lib.call("maavss_conv3d_c1_stats", 256, 256, 256, 256, 256, 1 << 15, 1 << 15, 1024, 1024, None)
     with pytest.raises(_lib.MaavssError, match="conv3d_c1_bn_pool_act"):
-        _lib.call("maavss_conv3d_c1_bn_pool_act", 256, 256, 256, 256, 256, 256, 256, None, None, 1, 1, 16, 16, None)   # argmax is required
+        _lib.call("maavss_conv3d_c1_bn_pool_act", 256, 256, 256, 256, 256, 256, 256, None, None, None, 1, 1, 16, 16, None)   # argmax is required
     with pytest.raises(_lib.MaavssError, match="pool must be 2 or 3"):
         _lib.call("maavss_conv3d_c1_wgrad_bn_recompute", 256, 256, 256, 256, 256, 256, 256, 256, 4, 256, 256, 8, 1, 1, 16, 16, 0, None)
     with pytest.raises(_lib.MaavssError, match="null pointer"):

@@ -168,6 +168,11 @@ def test_conv3d_16bit_operand_storage_is_bit_identical(ci, co, pad, b, t, h, w):
         dw32 = ops.conv3d_wgrad(x, dy, pad, ops.MODE_BF16)
         dw16 = ops.conv3d_wgrad(x, dy.to(torch.bfloat16), pad, ops.MODE_BF16)
         assert torch.equal(dw32, dw16)
+        if (ci, co) in ops.WGRAD_X16_SHAPES:      # x as the bf16 copy of its producer: both images by LDS-DMA, two image pairs
+            dwx = ops.conv3d_wgrad(x.to(torch.bfloat16), dy.to(torch.bfloat16), pad, ops.MODE_BF16)
+            assert torch.equal(dw32, dwx)
+            dwx3 = ops.conv3d_wgrad(x.to(torch.bfloat16), dy.to(torch.bfloat16), pad, ops.MODE_BF16, nchunk=3)      # several tiles per chunk: both pairs used
+            torch.testing.assert_close(dwx3, dw32, rtol=1e-5, atol=1e-6 * dw32.abs().max().item())
     if (co, ci) in ((32, 16), (64, 32), (64, 64), (16, 64), (16, 32), (32, 64)):      # dgrad instantiations
         wtd = ops.conv3d_prep(wgt, 1, ops.MODE_BF16)
         dx32, _ = ops.conv3d_igemm(dy, wtd, ci, 4 - pad, ops.MODE_BF16)
@@ -183,10 +188,13 @@ def test_bn_pool_act_16bit_side_outputs():
     part = ops.bn_stats(y, c)
     mean, invstd = ops.bn_finalize(part, b * t * h * w)
     gamma, beta = (1 + 0.3 * rnd(c, seed=2)).cuda(), (0.2 * rnd(c, seed=3)).cuda()
-    out, arg, out16 = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0, want16=True)
+    out, arg, out16, outb = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0, want16=True, want_bf16=True)
     out_b, arg_b = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0)
     assert torch.equal(out, out_b) and torch.equal(arg, arg_b)
     assert out16.dtype == torch.float16 and torch.equal(out16, out.half())
+    assert outb.dtype == torch.bfloat16 and torch.equal(outb, out.bfloat16())
+    _, _, only_b = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, pool, 0, want_bf16=True)
+    assert torch.equal(only_b, outb)
     dout = rnd(*out.shape, seed=4).cuda()
     dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
     dy32 = ops.bn_pool_act_bwd(dout, out, arg, y, mean, invstd, gamma, pool, 0, dgamma=dg, dbeta=db, beta=beta)
@@ -315,7 +323,8 @@ def test_conv3d_c1_without_the_stored_conv_output_is_bit_identical(b, t, h, w):
     assert torch.equal(part, part2)
     mean, invstd = ops.bn_finalize(part, b * t * h * w)
     out, arg, out16 = ops.bn_pool_act_fwd(y, mean, invstd, gamma, beta, 2, ops.BN_LEAKY, want16=True)
-    o2, a2, o16 = ops.conv3d_c1_bn_pool_act(x, wgt, mean, invstd, gamma, beta)
+    o2, a2, o16, ob = ops.conv3d_c1_bn_pool_act(x, wgt, mean, invstd, gamma, beta, want_bf16=True)
+    assert ob.dtype == torch.bfloat16 and torch.equal(ob, o2.bfloat16())
     assert torch.equal(out, o2) and torch.equal(arg, a2) and torch.equal(out16.view(torch.int16), o16.view(torch.int16))
     dout = rnd(*out.shape, seed=15).cuda()
     dg, db = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
