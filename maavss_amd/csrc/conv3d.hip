@@ -91,6 +91,17 @@ __device__ __forceinline__ TileId xcd_tile(int nx, int ny, int64_t total64) {
 }
 static inline int xcd_grid(int64_t total) { return (int)(((total + 7) / 8) * 8); }
 
+// Tile HEIGHT of the 16-wide output tiles (round 4): 14 rows when that covers the plane with as many tiles as 16 would (56 -> 4 x 14, 28 -> 2 x 14:
+// the layers at 56^2 and 28^2 spent 12.5 % of their MFMAs on rows below the image), else 16.  A tile's rows are dealt to the four waves as
+// 4 + 4 + 3 + 3 (first row 0, 4, 8, 11); the number of tiles -- and of BatchNorm partial rows -- is the same for both heights by construction.
+int maavss_conv_tile_h(int Ho) {      // (also conv3d_wgrad_wide.hip)
+  static const bool only16 = getenv("MAAVSS_TILE_H16") != nullptr;      // A/B switch
+  return !only16 && cdiv(Ho, 14) == cdiv(Ho, 16) ? 14 : 16;
+}
+static inline int conv_tile_h(int Ho) { return maavss_conv_tile_h(Ho); }
+__device__ __forceinline__ int tile_row0(int wv, int th) { return th == 14 ? 4 * wv - (wv > 2 ? wv - 2 : 0) : 4 * wv; }
+__device__ __forceinline__ int tile_nrows(int wv, int th) { return th == 14 && wv >= 2 ? 3 : 4; }
+
 // IN16: x is already stored in the MFMA operand format (IEEE half for the forward pass, bf16 for the input-gradient pass:
 // the producers bn_pool_act_fwd / bn_pool_act_bwd round once instead of every consumer) -- the halo is then a plain copy of
 // half the bytes: by LDS-DMA for C_in = 16 / 32 (no staging registers: these variants are VGPR-limited and ran a
@@ -99,7 +110,7 @@ template <int PRECISE, int CIN, int COUT, bool IN16 = false>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restrict__ x_,
                                                            const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                            float* __restrict__ y, float* __restrict__ stat_partials,
-                                                           int n_bt, int T, int H, int W, int Ho, int Wo, int pad, int KP) {
+                                                           int n_bt, int T, int H, int W, int Ho, int Wo, int pad, int KP, int th) {
   using M = Mma<PRECISE>;
   static_assert(!IN16 || PRECISE != MODE_F32, "16-bit input needs a 16-bit MFMA mode");
   const float* x = reinterpret_cast<const float*>(x_);
@@ -120,11 +131,15 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   E* wl = halo + 400 * CH;                                      // [2][COUT][64] swizzled
   float* red = reinterpret_cast<float*>(wl + 2 * COUT * 64);    // [4][2][COUT] stats scratch
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l16 = lane & 15;
-  const TileId tile = xcd_tile((Wo + 15) / 16, (Ho + 15) / 16, (int64_t)((Wo + 15) / 16) * ((Ho + 15) / 16) * n_bt);
+  const int ny = (Ho + th - 1) / th;
+  const TileId tile = xcd_tile((Wo + 15) / 16, ny, (int64_t)((Wo + 15) / 16) * ny * n_bt);
   if (!tile.valid) return;
-  const int x0 = tile.tx * 16, y0 = tile.ty * 16;
+  const int x0 = tile.tx * 16, y0 = tile.ty * th;
+  const int row0 = tile_row0(wv, th);
+  const bool four = tile_nrows(wv, th) == 4;      // wave-uniform: the wave's fourth row exists
+  const int hpos = (th + 4) * 20;                 // halo positions of a tile
   const int bt = tile.bt, t = bt % T;
   f32x4 acc[4][NT];
 #pragma unroll
@@ -192,9 +207,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
       // wave stays whole, the destination base stays lane 0's.
       const unsigned short* xp = x16 + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
       const unsigned short* zeros = reinterpret_cast<const unsigned short*>(wt) + 25 * CIN;
-      for (int i0 = 0; i0 < HV; i0 += 256) {
+      const int hv_rt = hpos * NCH;               // (th + 4) halo rows
+      for (int i0 = 0; i0 < hv_rt; i0 += 256) {
         const int i = i0 + tid;
-        if (i < HV) {
+        if (i < hv_rt) {
           const int pos = i / NCH, pc = i % NCH;
           const int r = pos / 20, c = pos % 20;
           const int iy = y0 + r - pad, ix = x0 + c - pad;
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
       }
     } else {
       const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
-      for (int i = tid; i < HV; i += 256) {
+      for (int i = tid; i < hpos * (CH / 4); i += 256) {
         const int pos = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
         const int r = pos / 20, c = pos % 20;
         const int iy = y0 + r - pad, ix = x0 + c - pad;
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
         typename M::frag fa[4], fb[NT];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = wv * 4 + i + kh, c = l16 + kw;
+          const int r = row0 + i + kh, c = l16 + kw;
           const E* base = halo + (r * 20 + c) * NCH * EPC;
           if constexpr (PRECISE == MODE_F32) {
             fa[i].lo = *reinterpret_cast<const f32x4*>(base + swz_halo<RBH, ES>(c, ci / EPC) * EPC);
@@ -280,8 +296,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+          if (i < 3 || four) {
 #pragma unroll
-          for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[i], fb[j]);
+            for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[i], fb[j]);
+          }
       }
       if (ch + 1 < NCHUNK) {
         E* wn = wl + ((ch + 1) & 1) * COUT * 64;
@@ -304,11 +322,11 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int oy = y0 + wv * 4 + i;
+    const int oy = y0 + row0 + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ox = x0 + g * 4 + r;
-      if (oy < Ho && ox < Wo) {
+      if ((i < 3 || four) && oy < Ho && ox < Wo) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float v = acc[i][j][r];
@@ -341,11 +359,12 @@ template <int PRECISE, int CIN, int COUT, bool IN16 = false>
 static int launch_igemm(const void* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho,
                         int Wo, int pad, int KP, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
+  const int th = conv_tile_h(Ho);
   const size_t smem = (400 * (PRECISE != MODE_F32 && CIN == 64 ? 32 : CIN) + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
   auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT, IN16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
-  hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP);
+  const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, th) * B * T;
+  hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP, th);
   return 0;
 }
 
@@ -369,7 +388,7 @@ __device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_
 template <int PRECISE, int CIN, int COUT, bool IN16>
 __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restrict__ x_, const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                              float* __restrict__ y, float* __restrict__ stat_partials, int n_bt, int T, int H,
-                                                             int W, int Ho, int Wo, int pad, int KP) {
+                                                             int W, int Ho, int Wo, int pad, int KP, int th) {
   using M = Mma<PRECISE>;
   using E = typename M::elem;
   static_assert(PRECISE != MODE_F32 && sizeof(E) == 2, "16-bit MFMA modes only");
@@ -389,11 +408,15 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
   const float* x = reinterpret_cast<const float*>(x_);
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x_);
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l16 = lane & 15;
-  const TileId tile = xcd_tile((Wo + 15) / 16, (Ho + 15) / 16, (int64_t)((Wo + 15) / 16) * ((Ho + 15) / 16) * n_bt);
+  const int ny = (Ho + th - 1) / th;
+  const TileId tile = xcd_tile((Wo + 15) / 16, ny, (int64_t)((Wo + 15) / 16) * ny * n_bt);
   if (!tile.valid) return;
-  const int x0 = tile.tx * 16, y0 = tile.ty * 16;
+  const int x0 = tile.tx * 16, y0 = tile.ty * th;
+  const int row0 = tile_row0(wv, th);
+  const bool four = tile_nrows(wv, th) == 4;      // wave-uniform: the wave's fourth row exists
+  const int hpos = (th + 4) * 20;                 // halo positions of a tile
   const int bt = tile.bt, t = bt % T;
   f32x4 acc[4][NT];
 #pragma unroll
@@ -407,10 +430,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
 #pragma unroll
     for (int kw = 0; kw < 5; ++kw) {
       const int c = l16 + kw;
-      a_off[kw] = (unsigned)(((4 * wv * 20 + c) * NCH + swz_halo<PB, 2>(c, g)) * 16);
+      a_off[kw] = (unsigned)(((row0 * 20 + c) * NCH + swz_halo<PB, 2>(c, g)) * 16);
     }
   } else {
-    a_off[0] = (unsigned)(((4 * wv * 20 + l16) * NCH + (g & 1)) * 16);      // + tap offset of the lane's half of the step
+    a_off[0] = (unsigned)(((row0 * 20 + l16) * NCH + (g & 1)) * 16);      // + tap offset of the lane's half of the step
   }
   // B (weight tile): row n = 16 j + l16, chunk 4 s + g of the row, swizzled with (n >> 1) & 7 = (l16 >> 1) & 7
   unsigned b_off[2];
@@ -442,8 +465,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
   auto mfmas = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
+      if (i < 3 || four) {       // (the fourth row's fragment is read either way: inside the 20-row halo allocation)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[set][i], fb[set][j]);
+        for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[set][i], fb[set][j]);
+      }
   };
 
   // ---- weight tiles: piece i of a tile = 16 bytes (row n = i / 8, chunk c = i % 8)
@@ -481,9 +506,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
       const unsigned short* zeros = reinterpret_cast<const unsigned short*>(wt) + 25 * CIN;
       int tv = tid;
       asm volatile("" : "+v"(tv));   // the index arithmetic is redone per stage: hoisted out of the stage loop it costs 60 registers
-      for (int i0 = 0; i0 < 400 * NCH; i0 += 256) {
+      for (int i0 = 0; i0 < hpos * NCH; i0 += 256) {
         const int i = i0 + tv;
-        if (i < 400 * NCH) {
+        if (i < hpos * NCH) {
           const int pos = i / NCH, pc = i % NCH;
           const int r = pos / 20, c = pos % 20;
           const int iy = y0 + r - pad, ix = x0 + c - pad;
@@ -497,7 +522,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
       const float* xp = x + (int64_t)(bt + kd - 1) * H * W * CIN + hh * CH;
       int tv = tid;
       asm volatile("" : "+v"(tv));
-      for (int i = tv; i < 400 * (CH / 4); i += 256) {
+      for (int i = tv; i < hpos * (CH / 4); i += 256) {
         const int pos = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
         const int r = pos / 20, c = pos % 20;
         const int iy = y0 + r - pad, ix = x0 + c - pad;
@@ -547,11 +572,11 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int oy = y0 + wv * 4 + i;
+    const int oy = y0 + row0 + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ox = x0 + g * 4 + r;
-      if (oy < Ho && ox < Wo) {
+      if ((i < 3 || four) && oy < Ho && ox < Wo) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float v = acc[i][j][r];
@@ -590,8 +615,9 @@ static int launch_igemm16(const void* x, const void* wt, float* y, float* stats,
     const size_t smem = 400 * (CIN == 64 ? 32 : CIN) * 2 + 3 * COUT * 128 + 8 * COUT * sizeof(float);
     auto kern = conv3d_igemm16_kernel<PRECISE, CIN, COUT, IN16>;
     if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T;
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP);
+    const int th = conv_tile_h(Ho);
+    const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, th) * B * T;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(tiles)), dim3(256), smem, st, x, reinterpret_cast<const E*>(wt), y, stats, B * T, T, H, W, Ho, Wo, pad, KP, th);
     return 0;
   }
 }

@@ -28,7 +28,7 @@ template <int MODE, int CI, int CO, int KDN, bool DY16 = false, int CIT = CI, bo
 __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __restrict__ x, const void* __restrict__ dy_,
                                                                float* __restrict__ partials, int BT, int T, int H, int W,
                                                                int Ho, int Wo, int pad, int tiles_x, int tiles_y,
-                                                               int tiles_per_chunk, int nchunk) {
+                                                               int tiles_per_chunk, int nchunk, int th) {
   using M = Mma<MODE>;
   using E = typename M::elem;
   constexpr int MT = CI / 16, NT = CO / 16, NTAP = KDN * 25, NPAIR = NTAP * MT, PW = (NPAIR + 7) / 8;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     if constexpr (X16) return;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y);
-    const int t = bt % T, x0 = tx * 16, y0 = ty * 16;
+    const int t = bt % T, x0 = tx * 16, y0 = ty * th;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int i = tid + j * 512;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
       const int pos = i / (CO / DVE), cv = (i % (CO / DVE)) * DVE;
       const int oy = y0 + pos / 16, ox = x0 + pos % 16;
       dr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < DV && oy < Ho && ox < Wo) {
+      if (i < DV && pos / 16 < th && oy < Ho && ox < Wo) {      // rows below the tile (th = 14): zeros
         const int64_t e = (int64_t)bt * Ho * Wo * CO + ((int64_t)oy * Wo + ox) * CO + cv;
         if constexpr (DY16) dr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(dy_) + e);
         else dr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + e);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   }
   auto dma = [&](int tile, int buf) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, bt = tile / (tiles_x * tiles_y);
-    const int t = bt % T, x0 = tx * 16, y0 = ty * 16;
+    const int t = bt % T, x0 = tx * 16, y0 = ty * th;
     const unsigned short* zeros = reinterpret_cast<const unsigned short*>(&wgw_zero16);
     const unsigned short* xb = x16 + (((int64_t)(bt + kd0 - 1) * H + (y0 - pad)) * W + (x0 - pad)) * CIT + ci0;
     E* xd = xs0 + buf * BUF;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
     for (int j = 0; j < NDD; ++j) {
       const int i = tid + 512 * j;
       const int oy = y0 + (dg[j] & 255), ox = x0 + (dg[j] >> 8);
-      const unsigned short* src = (oy < Ho && ox < Wo) ? db + dyo[j] : zeros;
+      const unsigned short* src = ((dg[j] & 255) < th && oy < Ho && ox < Wo) ? db + dyo[j] : zeros;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dd + (int64_t)i * 8), 16, 0, 0);
     }
@@ -205,9 +205,14 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
       __syncthreads();
       if (tile + 1 < tile_end) fetch(tile + 1);
     }
+    // K step = 32 positions of the tile: rows 2 ks, 2 ks + 1 x 16 columns -- or, when at most 8 columns of the tile are inside the image (the last
+    // tile column of a 56-wide plane), rows 4 ks .. 4 ks + 3 x 8 columns: half the steps (round 4).  th = 14: 7 / 4 steps (the dy rows below
+    // the tile are staged as zeros; the x image always holds 20 rows).
+    const int tx_cur = tile % tiles_x;
+    const bool half = PLANAR && Wo - tx_cur * 16 <= 8;      // wave-uniform
+    const int nks = half ? (th + 3) / 4 : th / 2, rstep = half ? 4 : 2, hrow = half ? 2 : 0, hcol = half ? 0 : 8;
 #pragma unroll 1
-    for (int ks = 0; ks < 8; ++ks) {
-      // K step = output rows 2ks, 2ks+1; k = 0..31 -> (row 2ks + k/16, col k%16)
+    for (int ks = 0; ks < nks; ++ks) {
       typename M::frag fb[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
           bf16x4 h[2];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const int row = 2 * ks + (G >> 1), col = 4 * (G & 1) + 8 * hh + (l16 >> 2);
+            const int row = rstep * ks + (G >> 1) + hh * hrow, col = 4 * (G & 1) + hh * hcol + (l16 >> 2);
             const E* a = ds + j * DP + (row * 16 + col) * 16 + (l16 & 3) * 4;
             h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
           }
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
           bf16x4 h[2];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const int row = 2 * ks + (G >> 1) + kh, col = 4 * (G & 1) + 8 * hh + (l16 >> 2) + kw;
+            const int row = rstep * ks + (G >> 1) + hh * hrow + kh, col = 4 * (G & 1) + hh * hcol + (l16 >> 2) + kw;
             const E* a = xb + (row * 20 + col) * 16 + (l16 & 3) * 4;
             h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
           }
@@ -306,6 +311,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_wide_kernel(const float* __r
   }
 }
 
+int maavss_conv_tile_h(int Ho);      // conv3d.hip
+
 template <int MODE, int CI, int CO, int KDN, bool DY16 = false, int CIT = CI, bool X16 = false>
 static void launch_wide(const float* x, const void* dy, float* ws, int BT, int T, int H, int W, int Ho, int Wo, int pad,
                         int nchunk, hipStream_t st) {
@@ -315,12 +322,14 @@ static void launch_wide(const float* x, const void* dy, float* ws, int BT, int T
                                    : (size_t)(KDN * (CI / 16) * (400 * 16 + 32) + (CO / 16) * (256 * 16 + 32)) * sizeof(E);
   auto kern = conv3d_wgrad_wide_kernel<MODE, CI, CO, KDN, DY16, CIT, X16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 16);
+  // tile height 14 where that covers the plane with as many tiles as 16 would (conv3d.hip, conv_tile_h): 56 -> 4 x 14, 28 -> 2 x 14
+  const int th = MODE != MODE_F32 ? maavss_conv_tile_h(Ho) : 16;
+  const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, th);
   const int tiles_total = BT * tiles_x * tiles_y;
   const int tpc = cdiv(tiles_total, nchunk);
   constexpr int KDG = 3 / KDN;
   hipLaunchKernelGGL(kern, dim3(KDG * cdiv(nchunk, 8) * 8, CIT / CI), dim3(512), smem, st, x, dy, ws, BT, T, H, W, Ho, Wo, pad, tiles_x,
-                     tiles_y, tpc, nchunk);
+                     tiles_y, tpc, nchunk, th);
 }
 
 // returns 1 if this (c_in, c_out) pair is handled by the wide kernel (and launches it), 0 otherwise
