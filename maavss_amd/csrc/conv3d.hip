@@ -128,8 +128,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
   constexpr int NCHUNK = (25 * CH + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   E* halo = reinterpret_cast<E*>(smem);                         // [20*20][CH] swizzled
-  E* wl = halo + 400 * CH;                                      // [2][COUT][64] swizzled
-  float* red = reinterpret_cast<float*>(wl + 2 * COUT * 64);    // [4][2][COUT] stats scratch
+  // 16-bit modes (round 4): the weight tiles go global -> LDS by DMA into a RING OF THREE, two chunks ahead of their use, instead of through
+  // registers one chunk ahead: at 56^2 / 28^2 these launches are bound by the 307 / 614 KB of weights every tile pulls through LDS, not by MFMAs
+  constexpr bool WDMA = PRECISE != MODE_F32;
+  constexpr int WSLOTS = WDMA ? 3 : 2;
+  E* wl = halo + 400 * CH;                                      // [WSLOTS][COUT][64] swizzled
+  float* red = reinterpret_cast<float*>(wl + WSLOTS * COUT * 64);    // [4][2][COUT] stats scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l16 = lane & 15;
@@ -240,19 +244,43 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
       if constexpr (HSPLIT) return wk + (int64_t)n * KP + (2 * q + c / 4) * 64 + hh * 32 + (c % 4) * EPC;
       else return wk + (int64_t)n * KP + q * 64 + c * EPC;
     };
-    for (int i = tid; i < COUT * NCW; i += 256) {
-      const int n = i / NCW, c = i % NCW;
-      *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) = *reinterpret_cast<const uint4*>(wsrc(i, 0));
+    constexpr int WV = (COUT * NCW + 255) / 256;
+    // DMA of chunk q into ring slot `slot`: lane-linear destination (piece i = row i / 8, physical chunk i % 8), swizzle on the source side
+    auto wdma = [&](int q, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int v = 0; v < WV; ++v) {
+        const int i = v * 256 + tid;
+        if (WV * 256 == COUT * NCW || i < COUT * NCW) {
+          const int n = i / NCW, pc = i % NCW;
+          const E* src = wsrc(n * NCW + swz<RBW>(n, pc), q);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(wl + slot * COUT * 64 + (int64_t)i * EPC), 16, 0, 0);
+        }
+      }
+    };
+    if constexpr (WDMA) {
+      wdma(0, 0);
+      if (NCHUNK > 1) wdma(1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo (DMA) and the first two weight tiles have landed
+      __syncthreads();
+    } else {
+      for (int i = tid; i < COUT * NCW; i += 256) {
+        const int n = i / NCW, c = i % NCW;
+        *reinterpret_cast<uint4*>(wl + (n * NCW + swz<RBW>(n, c)) * EPC) = *reinterpret_cast<const uint4*>(wsrc(i, 0));
+      }
+      if constexpr (IN16 && !PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo DMA has landed
+      __syncthreads();
     }
-    if constexpr (IN16 && !PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the halo DMA has landed
-    __syncthreads();
     if constexpr (PREFETCH) {
       if (kd < kd_hi) fetch(kd + 1);
     }
+    int slot = 0;
     for (int ch = 0; ch < NCHUNK; ++ch) {
-      constexpr int WV = (COUT * NCW + 255) / 256;
-      uint4 wreg[WV];
-      {
+      uint4 wreg[WDMA ? 1 : WV];
+      if constexpr (WDMA) {
+        // slot of chunk ch + 2 = slot of chunk ch - 1: every wave is past the barrier that ended it
+        if (ch + 2 < NCHUNK) wdma(ch + 2, slot == 0 ? 2 : slot - 1);
+      } else {
         // unconditional (clamped) loads keep wreg in registers: a conditionally written array lands in scratch
         const int chn = ch + 1 < NCHUNK ? ch + 1 : ch;
 #pragma unroll
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
           wreg[v] = *reinterpret_cast<const uint4*>(wsrc(i, chn));
         }
       }
-      const E* wb = wl + (ch & 1) * COUT * 64;
+      const E* wb = wl + (WDMA ? slot : (ch & 1)) * COUT * 64;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kk = ch * 64 + s * 32 + 8 * g;
@@ -301,18 +329,31 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const void* __restric
             for (int j = 0; j < NT; ++j) M::mma(acc[i][j], fa[i], fb[j]);
           }
       }
-      if (ch + 1 < NCHUNK) {
-        E* wn = wl + ((ch + 1) & 1) * COUT * 64;
+      if constexpr (WDMA) {
+        // chunk ch + 1 must have landed (this wave's pieces; the barrier collects the others'), chunk ch + 2 may stay in flight
+        if (ch + 2 < NCHUNK) {
+          if constexpr (WV == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+      } else {
+        if (ch + 1 < NCHUNK) {
+          E* wn = wl + ((ch + 1) & 1) * COUT * 64;
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
-          const int i = v * 256 + tid;
-          if (i < COUT * NCW) {
-            const int n = i / NCW, c = i % NCW;
-            *reinterpret_cast<uint4*>(wn + (n * NCW + swz<RBW>(n, c)) * EPC) = wreg[v];
+          for (int v = 0; v < WV; ++v) {
+            const int i = v * 256 + tid;
+            if (i < COUT * NCW) {
+              const int n = i / NCW, c = i % NCW;
+              *reinterpret_cast<uint4*>(wn + (n * NCW + swz<RBW>(n, c)) * EPC) = wreg[v];
+            }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   // ---- epilogue: store + optional per-block BatchNorm partial sums (sum, sum of squares per channel)
@@ -360,7 +401,7 @@ static int launch_igemm(const void* x, const void* wt, float* y, float* stats, i
                         int Wo, int pad, int KP, hipStream_t st) {
   using E = typename Mma<PRECISE>::elem;
   const int th = conv_tile_h(Ho);
-  const size_t smem = (400 * (PRECISE != MODE_F32 && CIN == 64 ? 32 : CIN) + 2 * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
+  const size_t smem = (400 * (PRECISE != MODE_F32 && CIN == 64 ? 32 : CIN) + (PRECISE != MODE_F32 ? 3 : 2) * COUT * 64) * sizeof(E) + 8 * COUT * sizeof(float);
   auto kern = conv3d_igemm_kernel<PRECISE, CIN, COUT, IN16>;
   if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int64_t tiles = (int64_t)cdiv(Wo, 16) * cdiv(Ho, th) * B * T;
