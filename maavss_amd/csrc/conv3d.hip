@@ -423,9 +423,9 @@ __device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_
 //     kw (32-channel stages) or one offset + a per-step select (16-channel stages: a 32-deep step spans two taps), the row / tap part is the
 //     ds_read's immediate -- no address arithmetic in the loop;
 //   * the fragments of step t + 1 are read before the MFMAs of step t (two register sets);
-//   * the weight chunks (64 k) go through a ring of three LDS tiles: chunk c + 2 is written while chunk c computes, so the fragments of the
-//     next chunk can be read before the barrier that ends this one; the barrier waits for LDS only (the global loads of chunk c + 3 are
-//     issued behind it and stay in flight for a whole chunk).
+//   * the weight chunks (64 k) go global -> LDS by DMA into a ring of four tiles, requested three chunks ahead, so the fragments of the next
+//     chunk can be read before the barrier that ends this one and a request has two chunks of time to land; the barrier waits for the
+//     request before the newest only.
 template <int PRECISE, int CIN, int COUT, bool IN16>
 __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restrict__ x_, const typename Mma<PRECISE>::elem* __restrict__ wt,
                                                              float* __restrict__ y, float* __restrict__ stat_partials, int n_bt, int T, int H,
@@ -444,8 +444,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
   constexpr int WV = (COUT * 8 + 255) / 256;          // 16-byte pieces of a weight tile per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;                                  // [400][PB], chunk-swizzled (swz_halo)
-  char* ring = smem + 400 * PB;                       // [3][COUT][128 B], chunk ^= (n >> 1) & 7
-  float* red = reinterpret_cast<float*>(ring + 3 * WB);
+  constexpr int RING = 4;
+  char* ring = smem + 400 * PB;                       // [RING][COUT][128 B], chunk ^= (n >> 1) & 7
+  float* red = reinterpret_cast<float*>(ring + RING * WB);
   const float* x = reinterpret_cast<const float*>(x_);
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x_);
 
@@ -512,26 +513,18 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
       }
   };
 
-  // ---- weight tiles: piece i of a tile = 16 bytes (row n = i / 8, chunk c = i % 8)
+  // ---- weight tiles by LDS-DMA: piece i of a tile = 16 bytes, lane-linear destination (row n = i / 8, PHYSICAL chunk i % 8): the swizzle is
+  // applied on the source side
   const int kd_lo = t == 0 ? 1 : 0, kd_hi = t == T - 1 ? 1 : 2;   // frames t + kd - 1 inside the clip (block-uniform)
-  uint4 wreg[WV];
-  auto w_load = [&](const E* wk, int hh, int q, uint4 (&dst)[WV]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int v = 0; v < WV; ++v) {
-      int i = v * 256 + tid;
-      i = i < COUT * 8 ? i : 0;                        // unconditional (clamped) loads keep the array in registers
-      const int n = i >> 3, c = i & 7;
-      const E* src = CIN == 64 ? wk + (int64_t)n * KP + (2 * q + (c >> 2)) * 64 + hh * 32 + (c & 3) * 8 : wk + (int64_t)n * KP + q * 64 + c * 8;
-      dst[v] = *reinterpret_cast<const uint4*>(src);
-    }
-  };
-  auto w_store = [&](int slot, const uint4 (&src)[WV]) __attribute__((always_inline)) {
+  auto wdma = [&](const E* wk, int hh, int q, int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < WV; ++v) {
       const int i = v * 256 + tid;
-      if (i < COUT * 8) {
-        const int n = i >> 3, c = i & 7;
-        *reinterpret_cast<uint4*>(ring + slot * WB + (n * 8 + (c ^ ((n >> 1) & 7))) * 16) = src[v];
+      if (WV * 256 == COUT * 8 || i < COUT * 8) {
+        const int n = i >> 3, c = (i & 7) ^ ((n >> 1) & 7);
+        const E* src = CIN == 64 ? wk + (int64_t)n * KP + (2 * q + (c >> 2)) * 64 + hh * 32 + (c & 3) * 8 : wk + (int64_t)n * KP + q * 64 + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ring + slot * WB + (int64_t)i * 16), 16, 0, 0);
       }
     }
   };
@@ -573,35 +566,35 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
         d[0] = M::cvt(v.x); d[1] = M::cvt(v.y); d[2] = M::cvt(v.z); d[3] = M::cvt(v.w);
       }
     }
-    // ---- weight chunks 0 and 1 of the stage into ring tiles 0 and 1, chunk 2 on its way
+    // ---- weight chunks 0 .. 2 of the stage into ring tiles 0 .. 2
     const E* wk = wt + (int64_t)kd * COUT * KP;
-    {
-      uint4 w0[WV];
-      w_load(wk, hh, 0, w0);
-      w_load(wk, hh, 1, wreg);
-      w_store(0, w0);
-      w_store(1, wreg);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // halo (DMA or stores) and the two tiles have landed
+    wdma(wk, hh, 0, 0);
+    if (NCHUNK > 1) wdma(wk, hh, 1, 1);
+    if (NCHUNK > 2) wdma(wk, hh, 2, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // halo (DMA or stores) and the three tiles have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (NCHUNK > 2) w_load(wk, hh, 2, wreg);
     load_frags(std::integral_constant<int, 0>{}, 0, 0u);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the K steps of the stage
+    // ---- the K steps of the stage.  Chunk c + 3 is requested when chunk c starts (its tile was chunk c - 1's: every wave is past the barrier
+    // that ended it) and has to be visible when chunk c + 1 ends (the fragments of chunk c + 2's first step are read there): two chunks of time.
     auto step = [&](auto st_c) __attribute__((always_inline)) {
       constexpr int st = decltype(st_c)::value;
       constexpr int c = st / 2;                        // chunk of this step
-      if constexpr (st + 1 < STEPS) load_frags(std::integral_constant<int, st + 1>{}, (st + 1) & 1, (unsigned)((((st + 1) / 2) % 3) * WB));
+      if constexpr ((st & 1) == 0 && c + 3 < NCHUNK) wdma(wk, hh, c + 3, (c + 3) % RING);
+      if constexpr (st + 1 < STEPS) load_frags(std::integral_constant<int, st + 1>{}, (st + 1) & 1, (unsigned)((((st + 1) / 2) % RING) * WB));
       __builtin_amdgcn_sched_barrier(0);
       mfmas(st & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((st & 1) || st + 1 == STEPS) {     // the chunk ends
-        if constexpr (c + 2 < NCHUNK) w_store((c + 2) % 3, wreg);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr ((st & 1) || st + 1 == STEPS) {     // the chunk ends: chunk c + 2 has landed (chunk c + 3 may stay in flight)
+        if constexpr (c + 3 < NCHUNK) {
+          if constexpr (WV == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (c + 3 < NCHUNK) w_load(wk, hh, c + 3, wreg);
       }
     };
     static_for<STEPS>(step);
@@ -649,11 +642,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm16_kernel(const void* __restr
 template <int PRECISE, int CIN, int COUT, bool IN16>
 static int launch_igemm16(const void* x, const void* wt, float* y, float* stats, int B, int T, int H, int W, int Ho, int Wo, int pad, int KP,
                           hipStream_t st) {
-  if constexpr (COUT > 32) {            // not instantiated: see maavss_conv3d_igemm
-    return launch_igemm<PRECISE, CIN, COUT, IN16>(x, wt, y, stats, B, T, H, W, Ho, Wo, pad, KP, st);
-  } else {
+  {
     using E = typename Mma<PRECISE>::elem;
-    const size_t smem = 400 * (CIN == 64 ? 32 : CIN) * 2 + 3 * COUT * 128 + 8 * COUT * sizeof(float);
+    const size_t smem = 400 * (CIN == 64 ? 32 : CIN) * 2 + 4 * COUT * 128 + 8 * COUT * sizeof(float);
     auto kern = conv3d_igemm16_kernel<PRECISE, CIN, COUT, IN16>;
     if (smem > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int th = conv_tile_h(Ho);
@@ -692,11 +683,9 @@ extern "C" int maavss_conv3d_igemm(const void* x, const void* wt, float* y, floa
   MAAVSS_CHECK_ARG((int64_t)cdiv(Wo, 16) * cdiv(Ho, 16) * B * T < (1LL << 31) - 8, "conv3d_igemm: too many output tiles");
   const int KP = maavss_conv3d_kp(c_in);
   hipStream_t st = (hipStream_t)stream;
-  // 16-bit modes: the pipelined kernel for C_out <= 32 (fwd 16->32 657 -> 585 us, dgrad 64->32 553 -> 520, dgrad 32->16 646 -> 565 at the benched
-  // shape, scripts/igemm_bench.py); with 64 output channels its two fragment sets + 64 accumulators do not fit three waves per SIMD (176-188
-  // registers, or spills) and the older loop -- 16 MFMAs per fragment set, three workgroups per CU -- stays 30 % faster.  MAAVSS_IGEMM_OLD=1: A/B switch.
-  static const bool env_old16 = getenv("MAAVSS_IGEMM_OLD") != nullptr;
-  const bool old16 = env_old16 || c_out > 32;
+  // 16-bit modes: the pipelined kernel (conv3d_igemm16_kernel); MAAVSS_IGEMM_OLD=1 = the round-1..3 loop, kept as the measured baseline
+  // (profiles/r4_igemm_bench.txt) and as the exact-f32 path
+  static const bool old16 = getenv("MAAVSS_IGEMM_OLD") != nullptr;
 #define CASE(CI, CO)                                                                                          \
   if (c_in == CI && c_out == CO) {                                                                            \
     if (precise == MODE_F32) launch_igemm<MODE_F32, CI, CO>(x, wt, y, stat_partials, B, T, H, W, Ho, Wo, pad, KP, st);      \
