@@ -105,55 +105,73 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 struct PoolGeom {
   int BT, T, H, W, C, p, Hp, Wp;
   int64_t osB, osT, osP, osC;  // element strides of the pooled output / its gradient
+  int lc4;                     // log2(C / 4)
+  int contig;                  // the pooled tensor is plain channels-last [BT][Hp][Wp][C]: element (position, c) sits at position * C + c
 };
+
+// Indexing of the three kernels below (round 4).  They were written as one flat grid-stride loop whose every element took its (bt, y, x, c)
+// apart with 64-bit divisions by runtime sizes: ~1000 instructions per 16-byte element in bwd_dx, 3400 per trip of bwd_reduce -- at 51 M
+// elements the vector work, not HBM, set their time (0.7 + 0.55 + 0.4 ms per step).  Now a workgroup walks ROWS (blockIdx-strided: bt and y
+// come from scalar divisions once per row), a thread's channel block is the same for every element it ever touches (256 is a multiple of C / 4:
+// the per-channel constants are loaded once), x is a shift, the pool size is a template constant, and offsets inside a row are 32-bit.
 
 __device__ __forceinline__ float act_fwd(float v, int act) { return act == ACT_TANH ? tanhf(v) : (v > 0.f ? v : 0.01f * v); }
 __device__ __forceinline__ float act_bwd_from_out(float out, int act) {
   return act == ACT_TANH ? 1.f - out * out : (out > 0.f ? 1.f : 0.01f);
 }
 
-// every thread handles 4 consecutive channels of one (pooled) position: float4 traffic on the channels-last side
+// every thread handles 4 consecutive channels of one (pooled) position: float4 traffic on the channels-last side; a workgroup walks pooled rows
+template <int P>
 __global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, unsigned char* __restrict__ argmax,
                                                               unsigned short* __restrict__ out16, unsigned short* __restrict__ out_bf16,
                                                               PoolGeom g, int act) {
-  const int C4 = g.C >> 2;
-  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    const int64_t pos = i / C4;
-    const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), is = *reinterpret_cast<const float4*>(invstd + c);
-    const float4 be = *reinterpret_cast<const float4*>(beta + c), mu = *reinterpret_cast<const float4*>(mean + c);
-    const float sc[4] = {ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w};
-    const float sh[4] = {be.x - mu.x * sc[0], be.y - mu.y * sc[1], be.z - mu.z * sc[2], be.w - mu.w * sc[3]};
-    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {0, 0, 0, 0};
-    const float* yp = y + (((int64_t)bt * g.H + (int64_t)py * g.p) * g.W + (int64_t)px * g.p) * g.C + c;
-    for (int dy = 0; dy < g.p; ++dy)
-      for (int dx = 0; dx < g.p; ++dx) {
-        const float4 v4 = *reinterpret_cast<const float4*>(yp + ((int64_t)dy * g.W + dx) * g.C);
-        const float v[4] = {v4.x * sc[0] + sh[0], v4.y * sc[1] + sh[1], v4.z * sc[2] + sh[2], v4.w * sc[3] + sh[3]};
+  const int C = g.C, C4 = C >> 2, tid = threadIdx.x;
+  const int c = (tid & (C4 - 1)) * 4;                 // the same for every element of this thread (256 % C4 == 0)
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 be = *reinterpret_cast<const float4*>(beta + c), mu = *reinterpret_cast<const float4*>(mean + c);
+  const float sc[4] = {ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w};
+  const float sh[4] = {be.x - mu.x * sc[0], be.y - mu.y * sc[1], be.z - mu.z * sc[2], be.w - mu.w * sc[3]};
+  const int rows = g.BT * g.Hp, n = g.Wp * C4;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {      // block-uniform: scalar arithmetic
+    const int bt = row / g.Hp, py = row - bt * g.Hp, b = bt / g.T, t = bt - b * g.T;
+    const float* yrow = y + ((int64_t)bt * g.H + (int64_t)py * P) * g.W * C + c;
+    const int64_t prow = (int64_t)row * g.Wp * C + c;              // channels-last pooled index of (row, column 0, c)
+    float* orow = out + (b * g.osB + t * g.osT + (int64_t)py * g.Wp * g.osP + c * g.osC);
+    for (int e = tid; e < n; e += 256) {
+      const int px = e >> g.lc4;
+      const float* yp = yrow + px * P * C;
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int bi[4] = {0, 0, 0, 0};
+      float4 v4[P * P];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (v[e] > best[e] || (v[e] != v[e] && best[e] == best[e])) { best[e] = v[e]; bi[e] = dy * g.p + dx; }
+      for (int dy = 0; dy < P; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < P; ++dx) v4[dy * P + dx] = *reinterpret_cast<const float4*>(yp + (dy * g.W + dx) * C);
+#pragma unroll
+      for (int q = 0; q < P * P; ++q) {
+        const float v[4] = {v4[q].x * sc[0] + sh[0], v4[q].y * sc[1] + sh[1], v4[q].z * sc[2] + sh[2], v4[q].w * sc[3] + sh[3]};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          if (v[e2] > best[e2] || (v[e2] != v[e2] && best[e2] == best[e2])) { best[e2] = v[e2]; bi[e2] = q; }      // q = dy * P + dx
       }
-    const int b = bt / g.T, t = bt % g.T;
-    float* op = out + b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
-    const float a4[4] = {act_fwd(best[0], act), act_fwd(best[1], act), act_fwd(best[2], act), act_fwd(best[3], act)};
-    if (g.osC == 1) {
-      *reinterpret_cast<float4*>(op) = make_float4(a4[0], a4[1], a4[2], a4[3]);
-    } else {
+      float* op = orow + px * g.osP;
+      const float a4[4] = {act_fwd(best[0], act), act_fwd(best[1], act), act_fwd(best[2], act), act_fwd(best[3], act)};
+      if (g.osC == 1) {
+        *reinterpret_cast<float4*>(op) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) op[e * g.osC] = a4[e];
+        for (int e2 = 0; e2 < 4; ++e2) op[e2 * g.osC] = a4[e2];
+      }
+      // the next Conv3d's forward MFMA rounds this activation to IEEE half when it stages it: done here once instead
+      // (same rounding, same value), so that its halo becomes a plain copy of half the bytes
+      const int64_t pi = prow + (int64_t)px * C;
+      if (out16 != nullptr) *reinterpret_cast<uint2*>(out16 + pi) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
+      if (out_bf16 != nullptr) *reinterpret_cast<uint2*>(out_bf16 + pi) = make_uint2(pack2<0>(a4[0], a4[1]), pack2<0>(a4[2], a4[3]));
+      if (argmax != nullptr) *reinterpret_cast<uchar4*>(argmax + pi) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
-    // the next Conv3d's forward MFMA rounds this activation to IEEE half when it stages it: done here once instead
-    // (same rounding, same value), so that its halo becomes a plain copy of half the bytes
-    if (out16 != nullptr) *reinterpret_cast<uint2*>(out16 + pos * g.C + c) = make_uint2(pack2<2>(a4[0], a4[1]), pack2<2>(a4[2], a4[3]));
-    if (out_bf16 != nullptr) *reinterpret_cast<uint2*>(out_bf16 + pos * g.C + c) = make_uint2(pack2<0>(a4[0], a4[1]), pack2<0>(a4[2], a4[3]));
-    if (argmax != nullptr) *reinterpret_cast<uchar4*>(argmax + pos * g.C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
   }
 }
 
@@ -188,6 +206,7 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
   if (gamma_inv != nullptr)
 #pragma unroll
     for (int e = 0; e < 4; ++e) inv[e] = fabsf(gamma_inv[c + e]) >= BN_INV_MIN_GAMMA;
+  const bool need_geo = !g.contig || !(inv[0] && inv[1] && inv[2] && inv[3]);      // strided pooled tensors, or channels that gather from y
   // four positions per trip, all their loads issued before the first use: with one position per trip a thread had one
   // dependent round trip to HBM in flight (the kernel streamed its 1.6 GB per step at 2.5 TB/s)
   constexpr int UB = 4;
@@ -198,9 +217,16 @@ __global__ __launch_bounds__(256) void bn_pool_act_bwd_reduce_kernel(
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int64_t pos = min(pos0 + (int64_t)u * nph, r1 - 1);      // clamped: the tail's duplicates are masked below
-      const int px = (int)(pos % g.Wp), py = (int)((pos / g.Wp) % g.Hp), bt = (int)(pos / ((int64_t)g.Wp * g.Hp));
-      const int b = bt / g.T, t = bt % g.T;
-      const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+      int px = 0, py = 0, bt = 0;
+      int64_t oi = pos * C + c;                                     // plain channels-last pooled tensors: no coordinates needed
+      if (need_geo) {                                                // 32-bit divisions (the entry point checks rows < 2^31)
+        const unsigned up = (unsigned)pos, q1 = up / (unsigned)g.Wp;
+        px = (int)(up - q1 * (unsigned)g.Wp);
+        bt = (int)(q1 / (unsigned)g.Hp);
+        py = (int)(q1 - (unsigned)bt * (unsigned)g.Hp);
+        const int b = bt / g.T, t = bt - b * g.T;
+        oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
+      }
       load4_strided(dout + oi, g.osC, dv[u]);
       load4_strided(out + oi, g.osC, ov[u]);
       bi4[u] = make_uchar4(0, 0, 0, 0);
@@ -260,49 +286,54 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   coef[2 * C + c] = (float)(s2 / count);
 }
 
-template <bool DY16>
+template <bool DY16, int P>
 __global__ __launch_bounds__(256) void bn_pool_act_bwd_dx_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const unsigned char* __restrict__ argmax,
     const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coef, void* __restrict__ dy_, PoolGeom g, int act) {
-  const int C = g.C, C4 = C >> 2;
-  const int64_t total = (int64_t)g.BT * g.H * g.W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    const int64_t pos = i / C4;
-    const int ix = (int)(pos % g.W), iy = (int)((pos / g.W) % g.H), bt = (int)(pos / ((int64_t)g.W * g.H));
-    const int py = iy / g.p, px = ix / g.p;
-    const float4 yv = *reinterpret_cast<const float4*>(y + pos * C + c);   // requested before the dependent argmax -> dout / out chain
-    float gg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (py < g.Hp && px < g.Wp) {
-      const int64_t ppos = ((int64_t)bt * g.Hp + py) * g.Wp + px;
-      const int here = (iy - py * g.p) * g.p + (ix - px * g.p);
-      uchar4 bi4 = make_uchar4(0, 0, 0, 0);
-      if (argmax != nullptr) bi4 = *reinterpret_cast<const uchar4*>(argmax + ppos * C + c);
-      const int bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
-      if (bi[0] == here || bi[1] == here || bi[2] == here || bi[3] == here) {
-        const int b = bt / g.T, t = bt % g.T;
-        const int64_t oi = b * g.osB + t * g.osT + ((int64_t)py * g.Wp + px) * g.osP + c * g.osC;
-        float dv[4], ov[4];
-        load4_strided(dout + oi, g.osC, dv);
-        load4_strided(out + oi, g.osC, ov);
+  const int C = g.C, C4 = C >> 2, tid = threadIdx.x;
+  const int c = (tid & (C4 - 1)) * 4;                 // the same for every element of this thread (256 % C4 == 0)
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 k0 = *reinterpret_cast<const float4*>(coef + c), k1 = *reinterpret_cast<const float4*>(coef + C + c);
+  const float4 k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+  const int rows = g.BT * g.H, n = g.W * C4;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {      // block-uniform: scalar arithmetic
+    const int bt = row / g.H, iy = row - bt * g.H, py = iy / P, b = bt / g.T, t = bt - b * g.T;
+    const bool prow_ok = py < g.Hp;
+    const int64_t rbase = (int64_t)row * g.W * C + c;              // element index of (row, column 0, c) in y / dy
+    const int64_t pbase = ((int64_t)bt * g.Hp + py) * g.Wp * C + c;                                   // the same in the (channels-last) argmax
+    const int64_t obase = b * g.osB + t * g.osT + (int64_t)py * g.Wp * g.osP + c * g.osC;             // ... in dout / out (their strides)
+    const int herey = (iy - py * P) * P;
+    for (int e = tid; e < n; e += 256) {
+      const int ix = e >> g.lc4, px = ix / P;
+      const float4 yv = *reinterpret_cast<const float4*>(y + rbase + (int64_t)ix * C);   // requested before the dependent argmax -> dout / out chain
+      float gg[4] = {0.f, 0.f, 0.f, 0.f};
+      if (prow_ok && px < g.Wp) {
+        const int here = herey + (ix - px * P);
+        uchar4 bi4 = make_uchar4(0, 0, 0, 0);
+        if (argmax != nullptr) bi4 = *reinterpret_cast<const uchar4*>(argmax + pbase + (int64_t)px * C);
+        const int bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+        if (bi[0] == here || bi[1] == here || bi[2] == here || bi[3] == here) {
+          const int64_t oi = obase + (int64_t)px * g.osP;
+          float dv[4], ov[4];
+          load4_strided(dout + oi, g.osC, dv);
+          load4_strided(out + oi, g.osC, ov);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (bi[e] == here) gg[e] = dv[e] * act_bwd_from_out(ov[e], act);
+          for (int e2 = 0; e2 < 4; ++e2)
+            if (bi[e2] == here) gg[e2] = dv[e2] * act_bwd_from_out(ov[e2], act);
+        }
       }
+      float4 o;
+      o.x = k0.x * (gg[0] - k1.x - (yv.x - mu.x) * is.x * k2.x);
+      o.y = k0.y * (gg[1] - k1.y - (yv.y - mu.y) * is.y * k2.y);
+      o.z = k0.z * (gg[2] - k1.z - (yv.z - mu.z) * is.z * k2.z);
+      o.w = k0.w * (gg[3] - k1.w - (yv.w - mu.w) * is.w * k2.w);
+      // DY16: both consumers of dy (the input-gradient and the weight-gradient MFMA kernels) round it to bf16 when they stage
+      // it -- rounded here once instead (bit-identical operands), written and re-read at half the bytes
+      const int64_t di = rbase + (int64_t)ix * C;
+      if constexpr (DY16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dy_) + di) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dy_) + di) = o;
     }
-    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
-    const float4 k0 = *reinterpret_cast<const float4*>(coef + c), k1 = *reinterpret_cast<const float4*>(coef + C + c);
-    const float4 k2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
-    float4 o;
-    o.x = k0.x * (gg[0] - k1.x - (yv.x - mu.x) * is.x * k2.x);
-    o.y = k0.y * (gg[1] - k1.y - (yv.y - mu.y) * is.y * k2.y);
-    o.z = k0.z * (gg[2] - k1.z - (yv.z - mu.z) * is.z * k2.z);
-    o.w = k0.w * (gg[3] - k1.w - (yv.w - mu.w) * is.w * k2.w);
-    // DY16: both consumers of dy (the input-gradient and the weight-gradient MFMA kernels) round it to bf16 when they stage
-    // it -- rounded here once instead (bit-identical operands), written and re-read at half the bytes
-    if constexpr (DY16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dy_) + pos * C + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
-    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(dy_) + pos * C + c) = o;
   }
 }
 
@@ -311,6 +342,7 @@ static int check_geom(const char* who, int B, int T, int H, int W, int C, int p)
   MAAVSS_CHECK_ARG(C >= 4 && C <= 64 && (C & (C - 1)) == 0, "%s: C must be a power of two in [4, 64] (got %d)", who, C);
   MAAVSS_CHECK_ARG(p >= 1 && p <= 3, "%s: pool must be 1, 2 or 3", who);
   MAAVSS_CHECK_ARG(H / p > 0 && W / p > 0, "%s: pooled size is zero", who);
+  MAAVSS_CHECK_ARG((int64_t)B * T * H < (1LL << 31) && (int64_t)B * T * (H / p) * (W / p) < (1LL << 31), "%s: too many rows for the 32-bit row arithmetic", who);
   return MAAVSS_OK;
 }
 
@@ -318,6 +350,9 @@ static PoolGeom make_geom(int B, int T, int H, int W, int C, int p, int64_t osB,
   PoolGeom g;
   g.BT = B * T; g.T = T; g.H = H; g.W = W; g.C = C; g.p = p; g.Hp = H / p; g.Wp = W / p;
   g.osB = osB; g.osT = osT; g.osP = osP; g.osC = osC;
+  g.lc4 = 0;
+  while ((4 << g.lc4) < C) ++g.lc4;
+  g.contig = osC == 1 && osP == C && osT == (int64_t)g.Hp * g.Wp * C && osB == (int64_t)T * osT;
   return g;
 }
 
@@ -382,9 +417,13 @@ extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const f
   if (int rc = check_geom("bn_pool_act_fwd", B, T, H, W, C, pool)) return rc;
   MAAVSS_CHECK_ARG(pool == 1 || argmax != nullptr, "bn_pool_act_fwd: argmax buffer required when pool > 1");
   PoolGeom g = make_geom(B, T, H, W, C, pool, os_b, os_t, os_p, os_c);
-  const int64_t total = (int64_t)g.BT * g.Hp * g.Wp * (C / 4);
-  hipLaunchKernelGGL(bn_pool_act_fwd_kernel, dim3(min((int64_t)8192, (total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, y, mean, invstd, gamma, beta, out, (unsigned char*)argmax, (unsigned short*)out16, (unsigned short*)out_bf16, g, act);
+  const dim3 grid(min(g.BT * g.Hp, 4096));      // a workgroup walks pooled rows
+#define FWD_LAUNCH(P) hipLaunchKernelGGL(bn_pool_act_fwd_kernel<P>, grid, dim3(256), 0, (hipStream_t)stream, y, mean, invstd, gamma, beta, out, \
+                                         (unsigned char*)argmax, (unsigned short*)out16, (unsigned short*)out_bf16, g, act)
+  if (pool == 1) FWD_LAUNCH(1);
+  else if (pool == 2) FWD_LAUNCH(2);
+  else FWD_LAUNCH(3);
+#undef FWD_LAUNCH
   MAAVSS_LAUNCH_CHECK("bn_pool_act_fwd_kernel");
   return MAAVSS_OK;
 }
@@ -392,10 +431,14 @@ extern "C" int maavss_bn_pool_act_fwd(const float* y, const float* mean, const f
 // ws: at least (2*C*nblk + 3*C) floats with nblk = maavss_bn_stats_nblk(B*T*Hp*Wp); coef = ws + 2*C*nblk
 #define BN_DX_LAUNCH()                                                                                                        \
   {                                                                                                                           \
-    const int64_t total = (int64_t)g.BT * H * W * (C / 4);                                                                    \
-    const dim3 grid(min((int64_t)8192, (total + 255) / 256));                                                                 \
-    if (dy_bf16) hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel<true>, grid, dim3(256), 0, st, dout, out, (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act); \
-    else hipLaunchKernelGGL(bn_pool_act_bwd_dx_kernel<false>, grid, dim3(256), 0, st, dout, out, (const unsigned char*)argmax, y, mean, invstd, coef, dy, g, act);       \
+    const dim3 grid(min(g.BT * H, 4096));      /* a workgroup walks rows */                                                   \
+    const unsigned char* am_ = (const unsigned char*)argmax;                                                                  \
+    if (dy_bf16 && g.p == 1) hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<true, 1>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act);      \
+    else if (dy_bf16 && g.p == 2) hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<true, 2>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act); \
+    else if (dy_bf16) hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<true, 3>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act);             \
+    else if (g.p == 1) hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<false, 1>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act);           \
+    else if (g.p == 2) hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<false, 2>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act);           \
+    else hipLaunchKernelGGL((bn_pool_act_bwd_dx_kernel<false, 3>), grid, dim3(256), 0, st, dout, out, am_, y, mean, invstd, coef, dy, g, act);                          \
     MAAVSS_LAUNCH_CHECK("bn_pool_act_bwd_dx_kernel");                                                                         \
   }
 
