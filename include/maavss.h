@@ -335,6 +335,13 @@ int maavss_vit_ws_gemm(const void* A, int lda, int64_t a_rows, const void* W, co
 int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float* row_stats, const float* ln_gamma, const float* ln_beta,
                           float ln_eps, const void* W, const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N,
                           int qscale_cols, float qscale, int dtype, void* stream);
+/* The same layer with the LayerNorm applied AFTER the product (round 4): the rows of X are only rounded to the storage format on the way in,
+ * W is the gamma-folded weight W diag(gamma) (storage format), col_sums[n] = sum over k of that ROUNDED W's row n (f32), bias = b + W beta, and the
+ * epilogue computes  rstd_r (x W^T - mean_r col_sums[n]) + bias[n]  (then the q-scale).  Equal to maavss_vit_ws_gemm_ln in exact arithmetic;
+ * in 16 bits another rounding realisation (raw rows rounded instead of normalised ones).  No per-element LayerNorm arithmetic in the loader. */
+int maavss_vit_ws_gemm_ln_post(const float* X, int64_t x_rows, const float* row_stats, const float* col_sums, float ln_eps, const void* W,
+                               const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N, int qscale_cols, float qscale, int dtype,
+                               void* stream);
 /* maavss_vit_gemm with the f32 epilogues (2, 3) additionally writing, for every row and every 128-column tile, (mean, sum of
  * squared deviations from that mean) of the values it stored: row_stats [M][N / 128][2] (null = maavss_vit_gemm). */
 int maavss_vit_gemm_stats(const void* A, int lda, const void* W, const float* bias, const float* table, int period, void* C,

@@ -5,8 +5,8 @@ The kernel loads the next activation panel with inline-asm global_load_dwordx4 i
 with its own `s_waitcnt vmcnt(N)` one loop iteration later (the compiler cannot see that the registers are pending).  That is
 only correct if, between a fetch and the wait that follows it, the compiler never touches those registers: no spill, no copy,
 no reuse.  This script proves it on the emitted ISA: every instruction whose nearest preceding asm block (in layout order,
-which is also execution order inside the single-loop kernel) is a FETCH must not mention a fetched register, and no kernel may
-use scratch.  The other half of the protocol is checked too: `s_waitcnt vmcnt(N)` only proves that the fetch has
+which is also execution order inside the single-loop kernel) is a FETCH must not mention a fetched register or use scratch (spills and
+reloads OUTSIDE a fetch span are tolerated: they cannot involve the fetch registers).  The other half of the protocol is checked too: `s_waitcnt vmcnt(N)` only proves that the fetch has
 landed if at least N vector-memory operations were issued AFTER it (vmcnt retires in issue order): the script counts the
 global_/buffer_/flat_ loads, stores and atomics between each fetch and its wait -- instructions inside an inner loop (a label
 with a backward branch inside that span: the two half-panel steps) count twice -- and fails if there are fewer than N, i.e. if
@@ -51,9 +51,6 @@ def main(path):
         return 1
     for name, body in funcs:
         lines = body.split("\n")
-        if any("scratch_" in ln for ln in lines):
-            print(f"{name}: uses scratch memory (register spills): the fetch registers may be spilled while their loads are in flight")
-            bad += 1
         state, pending, in_asm, block = "idle", set(), False, []
         n_fetch = n_wait = 0
         span = []                 # instructions (and labels) between the current fetch and its wait
@@ -94,6 +91,12 @@ def main(path):
                 span.append(t.split(";")[0].strip())
             if state == "pending" and t and not t.startswith(";") and not t.startswith("."):
                 code = t.split(";")[0]
+                if "scratch_" in code:
+                    # a spill or reload while a fetch is in flight: never accepted (a spill OUTSIDE a fetch span -- a loop-invariant value the
+                    # allocator parks before the loop and reloads at the top of a panel, round 4's LN = 5 variant -- cannot involve the fetch
+                    # registers, and extra vector-memory operations only make the counted waits stricter)
+                    print(f"{name}: `{code.strip()}` uses scratch memory while a panel fetch is in flight")
+                    bad += 1
                 hit = regs_of(code) & pending
                 if hit:
                     print(f"{name}: `{code.strip()}` touches v{sorted(hit)} while the panel fetch into them is in flight")

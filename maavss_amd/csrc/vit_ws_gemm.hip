@@ -86,8 +86,14 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // the affine part (ln_gamma = ln_beta = null: plain (x - mean) * rstd), for callers that fold gamma into the consumer GEMM's frozen weight columns
   // and beta into its bias (W' = W diag(gamma), b' = b + W beta): the deposit of norm1-on-the-way-in then costs two vector instructions per element
   // instead of three and no gamma / beta reads from LDS.  Measured in the step: +0.3 % (HISTORY.md H4) -- VideoAttention does not fold by default.
-  constexpr bool LN_OUT = LN == 1 || LN == 3, LN_IN = LN == 2 || LN == 4, AFF = LN == 1 || LN == 2;
-  static_assert(LN >= 0 && LN <= 4, "LN variant");
+  // LN = 5 (round 4, "LayerNorm after the product"): the rows arrive as f32 like LN = 2 / 4 but are only ROUNDED on the way in; the weights are the
+  // gamma-folded W' = W diag(gamma), and the epilogue applies the row statistics:  y = rstd_r (x W'^T - mean_r s_n) + b'_n  with s_n = sum_k W'[n][k]
+  // (g.ln_g, one per output column) and b' = b + W beta (g.bias) -- identical to LayerNorm(x) W^T + b in exact arithmetic.  The deposit is two
+  // conversions per four elements instead of the normalisation (which costs the step's attn.qkv launches a third of their time).
+  constexpr bool LN_POST = LN == 5;
+  constexpr bool LN_OUT = LN == 1 || LN == 3, LN_IN = LN == 2 || LN == 4 || LN_POST, AFF = LN == 1 || LN == 2;
+  static_assert(LN >= 0 && LN <= 5, "LN variant");
+  static_assert(!LN_POST || (SH == 16 && EPI == 0), "LayerNorm after the product: 16x16x32 form, 16-bit epilogue");
   static_assert(!LN_OUT || EPI == 2, "LayerNorm of the output rows comes with the residual epilogue");
   static_assert(!LN_IN || EPI == 0 || EPI == 3, "LayerNorm on the way in is wired for the attn.qkv epilogues");
   static_assert(EPI != 3 || LN_IN, "the MX epilogue is wired for attn.qkv (LayerNorm on the way in)");
@@ -196,10 +202,13 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   // 8 bytes to LDS (same swizzled image as the 16-bit path)
   auto deposit_ln_one = [&](char* dst, const float2* tab, int part, int i, const u32x4& raw, int ln) __attribute__((always_inline)) {
     const int q = (wv * 4 + i) * 64 + ln, r = q / 96, c4 = q - r * 96, rr = 32 * part + r;
-    const float2 ms = tab[rr];
+    float2 ms = make_float2(0.f, 0.f);
+    if constexpr (!LN_POST) ms = tab[rr];
     const float4 v = __builtin_bit_cast(float4, raw);
     uint2 o;
-    if constexpr (AFF) {
+    if constexpr (LN_POST) {
+      o = make_uint2(pack2<MODE>(v.x, v.y), pack2<MODE>(v.z, v.w));
+    } else if constexpr (AFF) {
       const float4 gg = *reinterpret_cast<const float4*>(gam_lds + 4 * c4), bb = *reinterpret_cast<const float4*>(bet_lds + 4 * c4);
       o = make_uint2(pack2<MODE>((v.x - ms.x) * ms.y * gg.x + bb.x, (v.y - ms.x) * ms.y * gg.y + bb.y),
                      pack2<MODE>((v.z - ms.x) * ms.y * gg.z + bb.z, (v.w - ms.x) * ms.y * gg.w + bb.w));
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
   if (tid < WS_SLICE) {
     bias_lds[tid] = g.bias[slice * WS_SLICE + tid];
     if constexpr (AFF) { gam_lds[tid] = g.ln_g[tid]; bet_lds[tid] = g.ln_b[tid]; }
+    if constexpr (LN_POST) gam_lds[tid] = g.ln_g[slice * WS_SLICE + tid];      // s_n of this workgroup's 384 output columns
   }
   if constexpr (!LN_IN) {
     WS_WAIT_FETCH(0)
@@ -315,11 +325,22 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
         // ================= 16x16x32 form: two 16-row blocks (c) x two 16-column blocks (b) of accumulators =================
         const char* pb16 = panels_lds + buf * WS_PANEL_BYTES + h2 * (32 * WS_K * 2) + frag16_r;
         f32x4 acc[2][2];
+        if constexpr (LN_POST) {
+          const float2* tab16 = table_lds + (it % 3) * WS_BM + 32 * h2 + j16;      // (mean, rstd) of this lane's rows (c = 0: [0], c = 1: [16])
+          const float nm0 = -tab16[0].x, nm1 = -tab16[16].x;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float4 bq = *reinterpret_cast<const float4*>(bias_lds + wv * 32 + cbase16 + CSTEP * b);
-          acc[0][b] = f32x4{bq.x, bq.y, bq.z, bq.w};
-          acc[1][b] = acc[0][b];
+          for (int b = 0; b < 2; ++b) {
+            const float4 sq = *reinterpret_cast<const float4*>(gam_lds + wv * 32 + cbase16 + CSTEP * b);
+            acc[0][b] = f32x4{nm0 * sq.x, nm0 * sq.y, nm0 * sq.z, nm0 * sq.w};      // - mean_r s_n: the MFMAs add x W'^T
+            acc[1][b] = f32x4{nm1 * sq.x, nm1 * sq.y, nm1 * sq.z, nm1 * sq.w};
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias_lds + wv * 32 + cbase16 + CSTEP * b);
+            acc[0][b] = f32x4{bq.x, bq.y, bq.z, bq.w};
+            acc[1][b] = acc[0][b];
+          }
         }
         // fragment t = 2 ks + c: rows 16 c .., k-step ks; it feeds the two MFMAs of column blocks b = 0, 1
         auto rd16 = [&](int t) __attribute__((always_inline)) {
@@ -359,6 +380,20 @@ __global__ __launch_bounds__(WS_THREADS) void vit_ws_gemm_kernel(WsArgs g) {
           for (int c = 0; c < 2; ++c) {
             bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (row0 + 16 * c) * g.ldc + n0 + 8 * g16;
             v2f v[4] = {v2f{acc[c][0][0], acc[c][0][1]}, v2f{acc[c][0][2], acc[c][0][3]}, v2f{acc[c][1][0], acc[c][1][1]}, v2f{acc[c][1][2], acc[c][1][3]}};
+            if constexpr (LN_POST) {      // rstd_r (x W'^T - mean_r s_n) + b'_n, scalar fmas (vit_epilogue.h); addresses redone here: nothing live across the MFMAs
+              int jj = lane;
+              asm volatile("" : "+v"(jj));
+              const float rs = table_lds[(it % 3) * WS_BM + 32 * h2 + 16 * c + (jj & 15)].y;
+              const float* bp = bias_lds + (tid >> 6) * 32 + 8 * (jj >> 4);
+              {
+                const float4 b0 = *reinterpret_cast<const float4*>(bp);
+                v[0].x = v[0].x * rs + b0.x; v[0].y = v[0].y * rs + b0.y; v[1].x = v[1].x * rs + b0.z; v[1].y = v[1].y * rs + b0.w;
+              }
+              {
+                const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+                v[2].x = v[2].x * rs + b1.x; v[2].y = v[2].y * rs + b1.y; v[3].x = v[3].x * rs + b1.z; v[3].y = v[3].y * rs + b1.w;
+              }
+            }
             if constexpr (EPI == 4) {
               *reinterpret_cast<uint4*>(cp) = make_uint4(pg_gelu_h2(v[0]), pg_gelu_h2(v[1]), pg_gelu_h2(v[2]), pg_gelu_h2(v[3]));
               continue;
@@ -699,6 +734,7 @@ static int ws_gemm_launch(const char* who, const void* A, const float* X, const 
     if (affine) { if (dtype == MODE_F16) WS_LAUNCH4(3, 2, MODE_F16, 32) else WS_LAUNCH4(3, 2, MODE_BF16, 32) }
     else { if (dtype == MODE_F16) WS_LAUNCH4(3, 4, MODE_F16, 32) else WS_LAUNCH4(3, 4, MODE_BF16, 32) }
   }
+  else if (X && epilogue == 5) { if (dtype == MODE_F16) WS_LAUNCH4(0, 5, MODE_F16, 16) else WS_LAUNCH4(0, 5, MODE_BF16, 16) }
   else if (X && affine) WS_LAUNCH(0, 2) else if (X) WS_LAUNCH(0, 4) else if (epilogue == 0) WS_LAUNCH(0, 0) else if (epilogue == 1) WS_LAUNCH(1, 0)
   else if (epilogue == 4) WS_LAUNCH3(4, 0, MODE_F16) else if (xn_out && affine) WS_LAUNCH(2, 1) else if (xn_out) WS_LAUNCH(2, 3) else WS_LAUNCH(2, 0)
 #undef WS_LAUNCH4
@@ -740,6 +776,23 @@ extern "C" int maavss_vit_ws_gemm_ln(const float* X, int64_t x_rows, const float
                    (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows, (long)c_rows);
   MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm_ln: ldc must be a multiple of 8, qscale_cols a multiple of 384");
   return ws_gemm_launch("vit_ws_gemm_ln", nullptr, X, row_stats, W, bias, C, ldc, M, N, 0, qscale_cols, qscale, nullptr, ln_gamma, ln_beta, ln_eps,
+                        dtype, stream);
+}
+
+// attn.qkv with the LayerNorm applied AFTER the product (kernel variant LN = 5): W = W diag(gamma) in the storage format, col_sums[n] = sum_k of
+// that (rounded) W's row n, bias = b + W beta.  Same result as maavss_vit_ws_gemm_ln in exact arithmetic, another rounding realisation in 16 bits
+// (the raw rows are rounded instead of the normalised ones).
+extern "C" int maavss_vit_ws_gemm_ln_post(const float* X, int64_t x_rows, const float* row_stats, const float* col_sums, float ln_eps, const void* W,
+                                          const float* bias, void* C, int ldc, int64_t c_rows, int64_t M, int N, int qscale_cols, float qscale,
+                                          int dtype, void* stream) {
+  MAAVSS_CHECK_ARG(X && row_stats && col_sums && W && bias && C && M > 0 && M < (1LL << 31), "vit_ws_gemm_ln_post: bad arguments");
+  MAAVSS_CHECK_ARG(N % WS_SLICE == 0 && N >= WS_SLICE, "vit_ws_gemm_ln_post: N must be a multiple of 384 (got %d)", N);
+  MAAVSS_CHECK_ARG(dtype == MODE_BF16 || dtype == MODE_F16, "vit_ws_gemm_ln_post: dtype must be 0 (bf16) or 2 (f16)");
+  MAAVSS_CHECK_ARG(x_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM && c_rows >= (int64_t)cdiv(M, WS_BM) * WS_BM,
+                   "vit_ws_gemm_ln_post: X and C need ceil(M/64)*64 = %ld allocated rows (got %ld, %ld): whole panels are read and stored",
+                   (long)cdiv(M, WS_BM) * WS_BM, (long)x_rows, (long)c_rows);
+  MAAVSS_CHECK_ARG(ldc % 8 == 0 && ldc >= N && qscale_cols % WS_SLICE == 0, "vit_ws_gemm_ln_post: ldc must be a multiple of 8, qscale_cols a multiple of 384");
+  return ws_gemm_launch("vit_ws_gemm_ln_post", nullptr, X, row_stats, W, bias, C, ldc, M, N, 5, qscale_cols, qscale, nullptr, col_sums, nullptr, ln_eps,
                         dtype, stream);
 }
 

@@ -101,7 +101,7 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
 class VideoAttention:
     def __init__(self, patch_size=8, threshold=0.6, path_to_weights="dino_deitsmall8_pretrain.pth",
                  architecture="vit_small", resize=None, device="cuda", frames_per_launch=512, act_dtype="f16",
-                 attn_dtype=None, fp8_blocks=None, gelu="f32"):
+                 attn_dtype=None, fp8_blocks=None, gelu="f32", qkv_ln=None):
         if patch_size != PATCH or architecture != "vit_small":
             raise ValueError("only DINO vit_small / patch 8 is built (the configuration the reference uses, "
                              "av_dataset.py:50)")
@@ -139,6 +139,16 @@ class VideoAttention:
         if gelu not in ("f32", "half") or (gelu == "half" and act_dtype != "f16"):
             raise ValueError("gelu must be 'f32' or 'half' (the latter with act_dtype='f16' only)")
         self.gelu_epilogue = 4 if gelu == "half" else EPI_BF16_BIAS_GELU
+        # qkv_ln (round 4): where norm1 is applied.  "pre" = on the way into the attn.qkv GEMM (the normalised rows are rounded to the storage
+        # format); "post" = AFTER the product: the raw rows are rounded, the weights are the gamma-folded W diag(gamma), and the epilogue applies
+        # rstd_r (x W'^T - mean_r s_n) + (b + W beta) -- the loader then has no per-element LayerNorm arithmetic (a third of the launch).  Same
+        # result in exact arithmetic, another rounding realisation in 16 bits (CPU oracle, end-to-end mask-MSE: 3.0e-6 / 4.7e-6 against 6.5e-6 / 3.1e-6
+        # of "pre" on the two seed sets tried).  Default: MAAVSS_QKV_LN (else "pre").
+        if qkv_ln is None:
+            qkv_ln = os.environ.get("MAAVSS_QKV_LN", "pre")
+        if qkv_ln not in ("pre", "post"):
+            raise ValueError("qkv_ln must be 'pre' or 'post'")
+        self.qkv_ln = qkv_ln
         self.checkpoint_key = "teacher"
         self.device = torch.device(device)
         self.frames_per_launch = frames_per_launch
@@ -188,6 +198,13 @@ class VideoAttention:
                             n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
                             fc1_w=bf(sd[p + "mlp.fc1.weight"]), fc1_b=f32(sd[p + "mlp.fc1.bias"]),
                             fc2_w=bf(sd[p + "mlp.fc2.weight"]), fc2_b=f32(sd[p + "mlp.fc2.bias"]))
+                if self.qkv_ln == "post":
+                    # W' = W diag(gamma) in the storage format, s_n = row sums of the ROUNDED W' (f32), b' = b + W beta (exact weights, f64 sums)
+                    w64 = sd[p + "attn.qkv.weight"].double()
+                    wf = bf((w64 * sd[p + "norm1.weight"].double()[None, :]).float())
+                    d[i]["qkv_wf"] = wf
+                    d[i]["qkv_cs"] = wf.float().sum(-1).contiguous()
+                    d[i]["qkv_bf"] = f32((sd[p + "attn.qkv.bias"].double() + w64 @ sd[p + "norm1.bias"].double()).float())
             self._dev = d
         return self._dev
 
@@ -260,8 +277,12 @@ class VideoAttention:
                          EPI_BF16_BIAS, DIM, qs, None, None, None, LN_EPS, dt, st)
                 else:
                   # norm1 + qkv: weights stationary in registers, x normalised on its way into LDS
-                  call("maavss_vit_ws_gemm_ln", ptr(x), rpad, ptr(stats), ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
-                       ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv, DIM, qs, dt, st)
+                  if self.qkv_ln == "post":
+                      call("maavss_vit_ws_gemm_ln_post", ptr(x), rpad, ptr(stats), ptr(b["qkv_cs"]), LN_EPS, ptr(b["qkv_wf"]), ptr(b["qkv_bf"]),
+                           ptr(qkv), 3 * DIM, rpad, rows, nqkv, DIM, qs, dt, st)
+                  else:
+                      call("maavss_vit_ws_gemm_ln", ptr(x), rpad, ptr(stats), ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),
+                           ptr(b["qkv_b"]), ptr(qkv), 3 * DIM, rpad, rows, nqkv, DIM, qs, dt, st)
             elif self.fused_panel_gemm:
                 # norm1 + qkv in one kernel (activation panel stationary in LDS, LayerNorm on the way in)
                 call("maavss_vit_panel_gemm", ptr(x), None, 0, ptr(b["n1w"]), ptr(b["n1b"]), LN_EPS, ptr(b["qkv_w"]),

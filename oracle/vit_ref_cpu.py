@@ -79,7 +79,8 @@ def interpolate_pos_embed(pos_embed, h_tok, w_tok):
     return torch.cat([pos_embed[:, :1], patch], 1)
 
 
-_ROUND = {"bf16": torch.bfloat16, "f16": torch.float16, "f16-gelu-half": torch.float16}   # the last: VideoAttention(gelu="half")
+# "f16-gelu-half": VideoAttention(gelu="half"); "...-lnpost": VideoAttention(qkv_ln="post") -- norm1 applied after the attn.qkv product
+_ROUND = {"bf16": torch.bfloat16, "f16": torch.float16, "f16-gelu-half": torch.float16, "f16-lnpost": torch.float16, "bf16-lnpost": torch.bfloat16}
 
 
 def _rounder(emulate):
@@ -178,8 +179,17 @@ def block_forward(sd, i, x, return_attention=False, emulate=None):
     p = f"blocks.{i}."
     b, n, _ = x.shape
     r = _rounder(emulate)
-    y = r(F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS))
-    qkv = F.linear(y, r(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"])
+    if emulate and str(emulate).endswith("-lnpost"):
+        # maavss_vit_ws_gemm_ln_post: raw rows rounded, weights W diag(gamma) rounded, row statistics applied behind the product
+        w64 = sd[p + "attn.qkv.weight"].double()
+        wf = r((w64 * sd[p + "norm1.weight"].double()[None, :]).float())
+        mu = x.mean(-1, keepdim=True)
+        rstd = (x.var(-1, unbiased=False, keepdim=True) + LN_EPS).rsqrt()
+        bprime = (sd[p + "attn.qkv.bias"].double() + w64 @ sd[p + "norm1.bias"].double()).float()
+        qkv = rstd * (F.linear(r(x), wf) - mu * wf.sum(-1)) + bprime
+    else:
+        y = r(F.layer_norm(x, (DIM,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS))
+        qkv = F.linear(y, r(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"])
     if emulate:
         qkv = r(torch.cat([qkv[..., :DIM] * QSCALE, qkv[..., DIM:]], -1))
     qkv = qkv.reshape(b, n, 3, HEADS, DIM // HEADS).permute(2, 0, 3, 1, 4)

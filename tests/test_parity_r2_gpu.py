@@ -193,6 +193,31 @@ def test_video_attention_matches_rounding_emulating_oracle(width, frames, act):
     assert rel <= lim_cls, rel
 
 
+@pytest.mark.parametrize("width,frames,act", [(64, 4, "f16"), (224, 2, "f16"), (64, 4, "bf16")])
+def test_video_attention_with_norm1_behind_the_qkv_product_matches_its_emulation(width, frames, act):
+    """VideoAttention(qkv_ln="post") (round 4): the attn.qkv GEMM runs on the rounded RAW rows with gamma-folded weights and applies the row
+    statistics in its epilogue.  Against the oracle that rounds exactly there (emulate="<act>-lnpost"), same limits as the default mode; its
+    distance to the fp32 oracle is printed next to the default mode's."""
+    import maavss_amd
+    from oracle import vit_ref_cpu as vref
+    sd = vref.seeded_vit_state(3)
+    va = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act, qkv_ln="post")
+    va.load_state_dict(sd)
+    va0 = maavss_amd.VideoAttention(path_to_weights="/nonexistent.pth", act_dtype=act, qkv_ln="pre")
+    va0.load_state_dict(sd)
+    fr = vref.synthetic_frames(frames, width, 5)
+    with torch.no_grad():
+        want_emu = vref.inference_ref(sd, fr, emulate=act + "-lnpost")
+        want_f32 = vref.inference_ref(sd, fr)
+    got, got0 = va._inference(fr), va0._inference(fr)
+    e_emu, e_f32, e0_f32 = (got - want_emu).abs().max().item(), (got - want_f32).abs().max().item(), (got0 - want_f32).abs().max().item()
+    print(f"[parity] ViT {act} {width}^2 qkv_ln=post: maps max|err| vs its rounding-emulating oracle {e_emu:.3e} (mean {(got - want_emu).abs().mean().item():.2e}); "
+          f"vs fp32 oracle {e_f32:.3e} mean {(got - want_f32).abs().mean().item():.2e} (qkv_ln=pre: {e0_f32:.3e} mean {(got0 - want_f32).abs().mean().item():.2e})")
+    lim_max, lim_mean = (5e-3, 5e-4) if act == "f16" else (4e-2, 5e-3)
+    assert e_emu <= lim_max, e_emu
+    assert (got - want_emu).abs().mean().item() <= lim_mean
+
+
 def test_grad_toggles_on_the_frames_model(golden_dir):
     """toggle_enc_grads / toggle_fusion_grads (avse_model_final.py:216-232): frozen parameters get no gradient, the
     others keep exactly the gradient of the unfrozen run (golden S)."""

@@ -261,6 +261,19 @@ def test_vit_ws_gemm_with_layernorm_on_the_way_in(m, n, dt):
     with pytest.raises(Exception, match="both given or both null"):
         _call("maavss_vit_ws_gemm_ln", xc.data_ptr(), mp, stats.data_ptr(), gc.data_ptr(), None, 1e-6, wc.data_ptr(), biasc.data_ptr(),
               c0.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    # LayerNorm applied AFTER the product (maavss_vit_ws_gemm_ln_post): raw rows rounded, folded weights, row statistics in the epilogue.
+    # Against its own arithmetic on the same rounded operands (tight), and against the LayerNorm-first result (two rounding realisations).
+    cs = wf.float().sum(-1)
+    csc = cs.cuda()
+    cp = torch.empty_like(c)
+    _call("maavss_vit_ws_gemm_ln_post", xc.data_ptr(), mp, stats.data_ptr(), csc.data_ptr(), 1e-6, wfc.data_ptr(), bfc.data_ptr(),
+          cp.data_ptr(), n, mp, m, n, 384, 0.125, dt, _st())
+    mu = x.mean(-1, keepdim=True)
+    rstd = (x.var(-1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+    want_p = rstd * (rd(x, dt).float() @ wf.float().t() - mu * cs[None, :]) + bf_
+    want_p[:, :384] *= 0.125
+    np.testing.assert_allclose(cp[:m].float().cpu().numpy(), want_p.numpy(), rtol=1.5e-2, atol=1.5e-2)
+    np.testing.assert_allclose(cp[:m].float().cpu().numpy(), want.numpy(), rtol=4e-2, atol=4e-2)
 
 
 def test_vit_layernorm_and_patchify():

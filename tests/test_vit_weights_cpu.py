@@ -63,7 +63,8 @@ def test_video_attention_mode_arguments_are_validated_on_the_host():
     assert VideoAttention(attn_dtype="fp8-late", **kw).fp8_blocks == frozenset((8, 9, 10))
     assert VideoAttention(attn_dtype="fp8", fp8_blocks=(9, 10), **kw).fp8_blocks == frozenset((9, 10))
     assert VideoAttention(gelu="half", **kw).gelu_epilogue == 4
+    assert VideoAttention(**kw).qkv_ln == "pre" and VideoAttention(qkv_ln="post", **kw).qkv_ln == "post"
     for bad in (dict(attn_dtype="fp4"), dict(fp8_blocks=(3,)), dict(attn_dtype="fp8", fp8_blocks=(11,)), dict(gelu="half", act_dtype="bf16"),
-                dict(gelu="tanh"), dict(act_dtype="fp32"), dict(patch_size=16)):
+                dict(gelu="tanh"), dict(act_dtype="fp32"), dict(patch_size=16), dict(qkv_ln="both")):
         with pytest.raises(ValueError):
             VideoAttention(**kw, **bad)
