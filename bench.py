@@ -506,7 +506,7 @@ def main():
                        "vit": args.vit_dtype, "vit_gelu": args.vit_gelu, "vit_qkv_ln": args.vit_qkv_ln, "vit_attention": ("block-scaled fp8 (MX e4m3, e8m0 scale per 32; f32 accumulate -- wider than the config's bf16)" + (" in blocks 8-10, " + args.vit_dtype + " in blocks 0-7" if args.attn_dtype == "fp8-late" else "")) if args.attn_dtype != "same" else args.vit_dtype, "conv_fwd": "f32" if args.precise else "f16", "conv_bwd": "f32" if args.precise else "bf16",
                        "end_to_end_mask_mse_vs_fp32_reference_chain": ("3.0e-3 ... 5.7e-3 over four seed sets (tests/test_parity_r2_gpu.py[fp8], tests/test_parity_r3_gpu.py, shape P; e4m3 operands: a throughput mode; "
                                                                        "per-operand / per-block table: profiles/r4_fp8_operand_ablation.txt -- the error is made in blocks 0-5, no all-block fp8 point is within 1e-4)" if args.attn_dtype == "fp8"
-                                                                    else "3.7e-5 ... 4.9e-5, gated <= 1e-4 (tests/test_parity_r4_gpu.py; profiles/r4_fp8_operand_ablation.txt: only late blocks stay below 1e-4, no operand subset over all blocks does).  Speed: 3 of 11 blocks in fp8 is within noise of the f16 step (808 vs 813 clips/s same box, profiles/r4_fp8late_bench.json; all blocks: 821) -- no fp8 point is both inside 1e-4 and faster" if args.attn_dtype == "fp8-late"
+                                                                    else "3.7e-5 ... 4.9e-5, gated <= 1e-4 (tests/test_parity_r4_gpu.py; profiles/r4_fp8_operand_ablation.txt: only late blocks stay below 1e-4, no operand subset over all blocks does).  Speed: 3 of 11 blocks in fp8 is within noise of the f16 step (808 vs 813 and 839 vs 834 clips/s on two boxes, profiles/r4_fp8late_bench.json, r4_g_fp8late_bench.json; all blocks: 821 / 855, +1 ... 2.5 %) -- no fp8 point is both inside 1e-4 and faster" if args.attn_dtype == "fp8-late"
                                                                     else ("3.0e-6 ... 6.5e-6 over five seed sets, shape P and the benched shape" if args.vit_dtype == "f16" else "2.3e-4 (shape P)") + " (tests/test_parity_r2_gpu.py, tests/test_parity_r3_gpu.py; target 1e-5)"),
                        "linear_lstm": "f32" + (" (deterministic: no atomic split-K)" if args.deterministic else " (split-K by f32 atomics)"), "batchnorm": "global-batch (sync)" if (args.sync_bn and world > 1) else "per-rank", "grad_all_reduce": f"{args.grad_wire} wire, per-module buckets in backward order",
                        "loss": loss_val},
